@@ -1,0 +1,122 @@
+/*
+ * tome_hip.h -- C ABI of the MI355X (gfx950) ToMe merge path.
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no torch types.  Every entry point is
+ * asynchronous on the caller's HIP stream, allocates nothing, never synchronises and returns a
+ * status (0 = ok).  All pointers are DEVICE pointers owned by the caller.
+ *
+ * The reference (sjpollard/video-how-do-your-tokens-merge) is pure Python/PyTorch, so its "FFI"
+ * for this path is the function interface of tome/merge.py; each entry below names the reference
+ * lines it replaces.  INTEGRATION.md shows the ctypes binding a maintainer of the reference would
+ * add (it is the binding video-how-do-your-tokens-merge_amd/tome/_abi.py uses).
+ *
+ * Index conventions (merge.py:52,64-73): tokens with even position are set A ("src
+ * candidates", row i = t/2, T1 = ceil(T/2) rows), odd positions are set B ("dst", row j = t/2,
+ * T2 = floor(T/2) rows).  src_idx / unm_idx hold A rows, dst_idx holds B rows, all int64 like the
+ * reference's closure variables ([n,r,1] / [n,T1-r,1], trailing 1 implicit here).
+ */
+#ifndef TOME_HIP_H
+#define TOME_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void *tome_stream_t; /* hipStream_t */
+
+enum tome_dtype { TOME_F32 = 0, TOME_BF16 = 1, TOME_F16 = 2 };
+
+/* reduce argument of torch.Tensor.scatter_reduce as used by merge(x, mode) -- merge.py:80 */
+enum tome_mode { TOME_SUM = 0, TOME_MEAN = 1, TOME_AMAX = 2, TOME_PROD = 3, TOME_AMIN = 4 };
+
+enum tome_status {
+    TOME_OK = 0,
+    TOME_EINVAL = 1,     /* bad argument (shape, dtype, null pointer, misaligned index buffer) */
+    TOME_EWORKSPACE = 2, /* workspace smaller than tome_match_workspace_bytes() */
+    TOME_ELAUNCH = 3     /* HIP reported a launch error (text in tome_last_error()) */
+};
+
+#define TOME_ABI_VERSION 1
+
+int tome_abi_version(void);
+
+/* Thread-local text of the last non-zero status returned on this thread. */
+const char *tome_last_error(void);
+
+/* merge.py:36-47 -- r clamped to half of the unprotected tokens; <= 0 means "do nothing". */
+int64_t tome_effective_r(int64_t T, int64_t r, int class_token, int distill_token);
+
+/* Bytes of scratch tome_match needs for a [n,T,D] metric. */
+size_t tome_match_workspace_bytes(int64_t n, int64_t T, int64_t D);
+
+/*
+ * tome_match  <-  bipartite_soft_matching, index part (merge.py:49-73; identical code in
+ *                 bipartite_soft_matching_drop :236-251 and _hybrid :296-311).
+ *
+ * metric: [n,T,D] of `dtype`, element strides (stride_n, stride_t, 1) -- a strided view such as
+ *         timesformer.py:83 `k.mean(1)[:, 1:, :]` needs no copy.
+ * r:      the caller's r; the call clamps it itself (tome_effective_r) and the index buffers must
+ *         be sized for the clamped value: src_idx, dst_idx [n, r_eff], unm_idx [n, T1 - r_eff].
+ * node_max: optional [n,T1] fp32 (row maxima of the similarity matrix, merge.py:64; needed by
+ *         the hybrid threshold test merge.py:326).
+ * row_map:  optional [n,T1] int32: for every A row the row of the MERGED sequence it ends up in
+ *         (its own slot when unmerged, its destination's slot when merged).
+ * Arithmetic: metric is converted to fp32; unit vectors, the A.B^T similarity (fp32 MFMA, k-ordered
+ *         fma chain), first-index row argmax and a stable descending ranking -- the contract is
+ *         written out in oracle/tome_oracle.c and DESIGN.md.
+ * Returns TOME_OK also when r_eff <= 0 (nothing is written).
+ */
+int tome_match(const void *metric, int dtype, int64_t n, int64_t T, int64_t D, int64_t stride_n,
+               int64_t stride_t, int64_t r, int class_token, int distill_token, int64_t *src_idx,
+               int64_t *dst_idx, int64_t *unm_idx, float *node_max, int32_t *row_map,
+               void *workspace, size_t workspace_bytes, tome_stream_t stream);
+
+/*
+ * tome_match_scores  <-  the same selection from caller-made scores [n,T1,T2] fp32
+ *                        (merge.py:54-57 random_merge / :239-242 random_drop, scores = torch.rand).
+ */
+int tome_match_scores(const float *scores, int64_t n, int64_t T, int64_t r, int class_token,
+                      int distill_token, int64_t *src_idx, int64_t *dst_idx, int64_t *unm_idx,
+                      float *node_max, int32_t *row_map, void *workspace, size_t workspace_bytes,
+                      tome_stream_t stream);
+
+/* merge.py:326 -- edge_keep[n,r] = (node_max[src_idx[k]] >= threshold) as 0/1 bytes. */
+int tome_edge_keep(const float *node_max, const int64_t *src_idx, int64_t n, int64_t T, int64_t r,
+                   float threshold, uint8_t *edge_keep, tome_stream_t stream);
+
+/*
+ * tome_merge_wavg  <-  merge_wavg (merge.py:355-369) fused: x*size, the two "sum" merges, x/size.
+ *
+ * x [n,T,C] of x_dtype, contiguous.  size: NULL (ones, :362-363) or [n,T] of size_dtype.
+ * x_out [n,T-r,C] of x_dtype, size_out [n,T-r] of size_dtype.  r is the clamped r (> 0).
+ * edge_keep: NULL, or the hybrid flags (merge.py:326).
+ * Arithmetic in fp32 (products, then sequential adds from the destination's own term in src_idx
+ * order, then one division); results rounded once to the output dtype.
+ */
+int tome_merge_wavg(const void *x, int x_dtype, const void *size, int size_dtype, int64_t n,
+                    int64_t T, int64_t C, int64_t r, const int64_t *src_idx,
+                    const int64_t *dst_idx, const int64_t *unm_idx, int distill_token,
+                    const uint8_t *edge_keep, void *x_out, void *size_out, tome_stream_t stream);
+
+/* tome_merge  <-  merge(x, mode) closure (merge.py:75-85; hybrid :313-334 when edge_keep). */
+int tome_merge(const void *x, int dtype, int64_t n, int64_t T, int64_t C, int64_t r,
+               const int64_t *src_idx, const int64_t *dst_idx, const int64_t *unm_idx,
+               int distill_token, int mode, const uint8_t *edge_keep, void *out,
+               tome_stream_t stream);
+
+/* tome_drop  <-  drop(x) closure (merge.py:253-262): unmerged A rows then all B rows. */
+int tome_drop(const void *x, int dtype, int64_t n, int64_t T, int64_t C, int64_t r,
+              const int64_t *und_idx, int distill_token, void *out, tome_stream_t stream);
+
+/* tome_unmerge  <-  unmerge(x) closure (merge.py:87-100): x [n,T-r,C] -> out [n,T,C]. */
+int tome_unmerge(const void *x, int dtype, int64_t n, int64_t T, int64_t C, int64_t r,
+                 const int64_t *src_idx, const int64_t *dst_idx, const int64_t *unm_idx, void *out,
+                 tome_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TOME_HIP_H */

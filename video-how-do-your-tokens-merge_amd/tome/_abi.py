@@ -1,0 +1,276 @@
+"""ctypes binding of the C ABI in include/tome_hip.h (lib/libtome_hip.so, gfx950 only).
+
+There is no CPU path and no PyTorch fallback: if the shared library is missing or a tensor is not
+on a HIP device, the call raises.  PyTorch is used for device memory and streams only.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from typing import Optional
+
+import torch
+
+_PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB_PATH = os.environ.get("TOME_HIP_LIB", os.path.join(_PKG, "lib", "libtome_hip.so"))
+
+SYMBOLS = (
+    "tome_abi_version", "tome_last_error", "tome_effective_r", "tome_match_workspace_bytes", "tome_match",
+    "tome_match_scores", "tome_edge_keep", "tome_merge_wavg", "tome_merge", "tome_drop", "tome_unmerge",
+)
+
+ABI_VERSION = 1
+DTYPES = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}
+MODES = {"sum": 0, "mean": 1, "amax": 2, "max": 2, "prod": 3, "amin": 4, "min": 4}
+
+_lib = None
+
+
+class TomeHipError(RuntimeError):
+    pass
+
+
+def lib() -> ctypes.CDLL:
+    """Load libtome_hip.so once; fail loudly when it is absent (build it with
+    `python video-how-do-your-tokens-merge_amd/csrc/build.py`)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise TomeHipError(
+            f"HIP extension not found at {LIB_PATH}: the MI355X merge path has no fallback. "
+            "Build it with `python video-how-do-your-tokens-merge_amd/csrc/build.py` (needs hipcc).")
+    L = ctypes.CDLL(LIB_PATH)
+    i64, i32, vp, sz = ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t
+    L.tome_abi_version.restype = i32
+    L.tome_abi_version.argtypes = []
+    L.tome_last_error.restype = ctypes.c_char_p
+    L.tome_last_error.argtypes = []
+    L.tome_effective_r.restype = i64
+    L.tome_effective_r.argtypes = [i64, i64, i32, i32]
+    L.tome_match_workspace_bytes.restype = sz
+    L.tome_match_workspace_bytes.argtypes = [i64, i64, i64]
+    L.tome_match.restype = i32
+    L.tome_match.argtypes = [vp, i32, i64, i64, i64, i64, i64, i64, i32, i32, vp, vp, vp, vp, vp, vp, sz, vp]
+    L.tome_match_scores.restype = i32
+    L.tome_match_scores.argtypes = [vp, i64, i64, i64, i32, i32, vp, vp, vp, vp, vp, vp, sz, vp]
+    L.tome_edge_keep.restype = i32
+    L.tome_edge_keep.argtypes = [vp, vp, i64, i64, i64, ctypes.c_float, vp, vp]
+    L.tome_merge_wavg.restype = i32
+    L.tome_merge_wavg.argtypes = [vp, i32, vp, i32, i64, i64, i64, i64, vp, vp, vp, i32, vp, vp, vp, vp]
+    L.tome_merge.restype = i32
+    L.tome_merge.argtypes = [vp, i32, i64, i64, i64, i64, vp, vp, vp, i32, i32, vp, vp, vp]
+    L.tome_drop.restype = i32
+    L.tome_drop.argtypes = [vp, i32, i64, i64, i64, i64, vp, i32, vp, vp]
+    L.tome_unmerge.restype = i32
+    L.tome_unmerge.argtypes = [vp, i32, i64, i64, i64, i64, vp, vp, vp, vp, vp]
+    if L.tome_abi_version() != ABI_VERSION:
+        raise TomeHipError(f"libtome_hip.so ABI {L.tome_abi_version()} != expected {ABI_VERSION}")
+    _lib = L
+    return L
+
+
+def _check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = lib().tome_last_error().decode("utf-8", "replace")
+        raise TomeHipError(f"{what} failed (status {rc}): {msg}")
+
+
+def require_device(t: torch.Tensor, what: str) -> None:
+    if not t.is_cuda:
+        raise TomeHipError(
+            f"{what}: tensor is on {t.device}; this build runs only on a HIP device (MI355X) and has no CPU path")
+
+
+def dtype_code(t: torch.Tensor, what: str) -> int:
+    try:
+        return DTYPES[t.dtype]
+    except KeyError:
+        raise TomeHipError(f"{what}: dtype {t.dtype} not supported (float32, bfloat16, float16)") from None
+
+
+def _stream(device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+_workspaces = {}
+
+
+def _workspace(device, stream: int, nbytes: int) -> torch.Tensor:
+    key = (device.index, stream)
+    ws = _workspaces.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        _workspaces[key] = ws
+    return ws
+
+
+def effective_r(T: int, r: int, class_token: bool, distill_token: bool) -> int:
+    return int(lib().tome_effective_r(int(T), int(r), int(bool(class_token)), int(bool(distill_token))))
+
+
+class MatchPlan:
+    """Device-resident result of one matching: the reference's closure variables (int64,
+    [n,r,1] / [n,T1-r,1]) plus what the fused kernels want (node_max for the hybrid threshold,
+    row_map for source tracking)."""
+
+    __slots__ = ("n", "T", "r", "class_token", "distill_token", "src_idx", "dst_idx", "unm_idx", "node_max",
+                 "row_map", "edge_keep", "device")
+
+    def __init__(self, n, T, r, class_token, distill_token, src_idx, dst_idx, unm_idx, node_max, row_map, device):
+        self.n, self.T, self.r = n, T, r
+        self.class_token, self.distill_token = bool(class_token), bool(distill_token)
+        self.src_idx, self.dst_idx, self.unm_idx = src_idx, dst_idx, unm_idx
+        self.node_max, self.row_map = node_max, row_map
+        self.edge_keep = None
+        self.device = device
+
+
+def _alloc_plan(n, T, re, class_token, distill_token, device, want_node_max, want_row_map):
+    T1 = (T + 1) // 2
+    src = torch.empty((n, re, 1), dtype=torch.int64, device=device)
+    dst = torch.empty((n, re, 1), dtype=torch.int64, device=device)
+    unm = torch.empty((n, T1 - re, 1), dtype=torch.int64, device=device)
+    nmax = torch.empty((n, T1), dtype=torch.float32, device=device) if want_node_max else None
+    rmap = torch.empty((n, T1), dtype=torch.int32, device=device) if want_row_map else None
+    return MatchPlan(n, T, re, class_token, distill_token, src, dst, unm, nmax, rmap, device)
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def match(metric: torch.Tensor, r: int, class_token=False, distill_token=False, want_node_max=False,
+          want_row_map=False) -> Optional[MatchPlan]:
+    """tome_match on `metric` [n,T,D]; returns None when the clamped r is <= 0."""
+    require_device(metric, "bipartite_soft_matching(metric)")
+    if metric.dim() != 3:
+        raise TomeHipError(f"metric must be [batch, tokens, channels], got {tuple(metric.shape)}")
+    code = dtype_code(metric, "metric")
+    n, T, D = metric.shape
+    re = effective_r(T, r, class_token, distill_token)
+    if re <= 0 or n == 0:
+        return None
+    if metric.stride(2) != 1:
+        metric = metric.contiguous()
+    L = lib()
+    dev = metric.device
+    with torch.cuda.device(dev):
+        st = _stream(dev)
+        nbytes = L.tome_match_workspace_bytes(n, T, D)
+        ws = _workspace(dev, st, nbytes)
+        plan = _alloc_plan(n, T, re, class_token, distill_token, dev, want_node_max, want_row_map)
+        rc = L.tome_match(metric.data_ptr(), code, n, T, D, metric.stride(0), metric.stride(1), int(r),
+                          int(bool(class_token)), int(bool(distill_token)), plan.src_idx.data_ptr(),
+                          plan.dst_idx.data_ptr(), plan.unm_idx.data_ptr(), _ptr(plan.node_max), _ptr(plan.row_map),
+                          ws.data_ptr(), ws.numel(), st)
+    _check(rc, "tome_match")
+    return plan
+
+
+def match_scores(scores: torch.Tensor, T: int, r: int, class_token=False, distill_token=False,
+                 want_node_max=False, want_row_map=False) -> Optional[MatchPlan]:
+    require_device(scores, "match_scores(scores)")
+    n, T1, T2 = scores.shape
+    if T1 != (T + 1) // 2 or T2 != T // 2:
+        raise TomeHipError(f"scores shape {tuple(scores.shape)} does not fit T={T}")
+    re = effective_r(T, r, class_token, distill_token)
+    if re <= 0 or n == 0:
+        return None
+    scores = scores.float().contiguous()
+    L = lib()
+    dev = scores.device
+    with torch.cuda.device(dev):
+        st = _stream(dev)
+        nbytes = L.tome_match_workspace_bytes(n, T, 1)
+        ws = _workspace(dev, st, nbytes)
+        plan = _alloc_plan(n, T, re, class_token, distill_token, dev, want_node_max, want_row_map)
+        rc = L.tome_match_scores(scores.data_ptr(), n, T, int(r), int(bool(class_token)), int(bool(distill_token)),
+                                 plan.src_idx.data_ptr(), plan.dst_idx.data_ptr(), plan.unm_idx.data_ptr(),
+                                 _ptr(plan.node_max), _ptr(plan.row_map), ws.data_ptr(), ws.numel(), st)
+    _check(rc, "tome_match_scores")
+    return plan
+
+
+def edge_keep(plan: MatchPlan, threshold: float) -> torch.Tensor:
+    if plan.node_max is None:
+        raise TomeHipError("edge_keep needs a plan made with want_node_max=True")
+    keep = torch.empty((plan.n, plan.r), dtype=torch.uint8, device=plan.device)
+    with torch.cuda.device(plan.device):
+        rc = lib().tome_edge_keep(plan.node_max.data_ptr(), plan.src_idx.data_ptr(), plan.n, plan.T, plan.r,
+                                  float(threshold), keep.data_ptr(), _stream(plan.device))
+    _check(rc, "tome_edge_keep")
+    return keep
+
+
+def _prep_x(plan: MatchPlan, x: torch.Tensor, what: str, tokens: int) -> torch.Tensor:
+    require_device(x, what)
+    if x.dim() != 3 or x.shape[0] != plan.n or x.shape[1] != tokens:
+        raise TomeHipError(f"{what}: expected [{plan.n}, {tokens}, C], got {tuple(x.shape)}")
+    if x.device != plan.device:
+        raise TomeHipError(f"{what}: tensor on {x.device}, matching was computed on {plan.device}")
+    if torch.is_grad_enabled() and x.requires_grad:
+        raise TomeHipError(f"{what}: autograd through the HIP merge kernels is not implemented (inference path); "
+                           "call under torch.no_grad()")
+    return x if x.is_contiguous() else x.contiguous()
+
+
+def merge_wavg(plan: MatchPlan, x: torch.Tensor, size: Optional[torch.Tensor]):
+    x = _prep_x(plan, x, "merge_wavg(x)", plan.T)
+    n, T, C = x.shape
+    xcode = dtype_code(x, "x")
+    if size is not None:
+        require_device(size, "merge_wavg(size)")
+        if size.shape != (n, T, 1):
+            raise TomeHipError(f"size must be [{n}, {T}, 1], got {tuple(size.shape)}")
+        if size.dtype not in (x.dtype, torch.float32):
+            size = size.to(x.dtype)
+        size = size.contiguous()
+        sdtype = size.dtype
+    else:
+        sdtype = x.dtype  # torch.ones_like(x[..., 0, None]) -- merge.py:362-363
+    scode = DTYPES[sdtype]
+    x_out = torch.empty((n, T - plan.r, C), dtype=x.dtype, device=x.device)
+    s_out = torch.empty((n, T - plan.r, 1), dtype=sdtype, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = lib().tome_merge_wavg(x.data_ptr(), xcode, _ptr(size), scode, n, T, C, plan.r, plan.src_idx.data_ptr(),
+                                   plan.dst_idx.data_ptr(), plan.unm_idx.data_ptr(), int(plan.distill_token),
+                                   _ptr(plan.edge_keep), x_out.data_ptr(), s_out.data_ptr(), _stream(x.device))
+    _check(rc, "tome_merge_wavg")
+    return x_out, s_out
+
+
+def merge(plan: MatchPlan, x: torch.Tensor, mode: str) -> torch.Tensor:
+    if mode not in MODES:
+        raise TomeHipError(f"merge: unknown reduce mode {mode!r}")
+    x = _prep_x(plan, x, "merge(x)", plan.T)
+    n, T, C = x.shape
+    out = torch.empty((n, T - plan.r, C), dtype=x.dtype, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = lib().tome_merge(x.data_ptr(), dtype_code(x, "x"), n, T, C, plan.r, plan.src_idx.data_ptr(),
+                              plan.dst_idx.data_ptr(), plan.unm_idx.data_ptr(), int(plan.distill_token), MODES[mode],
+                              _ptr(plan.edge_keep), out.data_ptr(), _stream(x.device))
+    _check(rc, "tome_merge")
+    return out
+
+
+def drop(plan: MatchPlan, x: torch.Tensor) -> torch.Tensor:
+    x = _prep_x(plan, x, "drop(x)", plan.T)
+    n, T, C = x.shape
+    out = torch.empty((n, T - plan.r, C), dtype=x.dtype, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = lib().tome_drop(x.data_ptr(), dtype_code(x, "x"), n, T, C, plan.r, plan.unm_idx.data_ptr(),
+                             int(plan.distill_token), out.data_ptr(), _stream(x.device))
+    _check(rc, "tome_drop")
+    return out
+
+
+def unmerge(plan: MatchPlan, x: torch.Tensor) -> torch.Tensor:
+    x = _prep_x(plan, x, "unmerge(x)", plan.T - plan.r)
+    n, _, C = x.shape
+    out = torch.empty((n, plan.T, C), dtype=x.dtype, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = lib().tome_unmerge(x.data_ptr(), dtype_code(x, "x"), n, plan.T, C, plan.r, plan.src_idx.data_ptr(),
+                                plan.dst_idx.data_ptr(), plan.unm_idx.data_ptr(), out.data_ptr(), _stream(x.device))
+    _check(rc, "tome_unmerge")
+    return out

@@ -1,0 +1,155 @@
+"""ToMe token merging for MI355X -- same functions and signatures as the reference's
+``tome/merge.py``, with the arithmetic done by the hand-written gfx950 kernels behind the C ABI
+of ``include/tome_hip.h`` (see ``_abi.py``).
+
+Reference lines each function stands in for (sjpollard/video-how-do-your-tokens-merge):
+  bipartite_soft_matching         tome/merge.py:17-102
+  bipartite_soft_matching_drop    tome/merge.py:215-271
+  bipartite_soft_matching_hybrid  tome/merge.py:274-352
+  merge_wavg                      tome/merge.py:355-369
+  merge_source                    tome/merge.py:372-384
+  do_nothing                      tome/merge.py:13-14
+
+The returned ``merge`` / ``unmerge`` / ``drop`` are real closures over ``unm_idx``, ``src_idx``,
+``dst_idx`` (int64 device tensors shaped [n,r,1] / [n,T1-r,1]) and ``r`` exactly like the reference's,
+so code that introspects them keeps working; they also carry ``.plan`` for the fused paths.
+
+Tensors must live on a HIP device: there is no CPU implementation in this package.
+"""
+from __future__ import annotations
+
+from typing import Callable, Optional, Tuple
+
+import torch
+
+from . import _abi
+
+
+def do_nothing(x, mode=None):
+    return x
+
+
+def _scores_for_random(metric: torch.Tensor) -> torch.Tensor:
+    """merge.py:54-57 / :239-242 -- the random variants replace the similarity by uniform noise drawn on
+    the metric's device (torch's generator, exactly as the reference draws it)."""
+    length = metric.size(1)
+    len_a, len_b = (length + 1) // 2, length // 2
+    return torch.rand(size=(metric.size(0), len_a, len_b), device=metric.device)
+
+
+def _plan(metric, r, class_token, distill_token, random: bool, **want) -> Optional[_abi.MatchPlan]:
+    with torch.no_grad():
+        if random:
+            _abi.require_device(metric, "bipartite_soft_matching(metric)")
+            t = metric.shape[1]
+            if _abi.effective_r(t, r, class_token, distill_token) <= 0:
+                return None
+            return _abi.match_scores(_scores_for_random(metric), t, r, class_token, distill_token, **want)
+        return _abi.match(metric, r, class_token, distill_token, **want)
+
+
+def bipartite_soft_matching(
+    metric: torch.Tensor,
+    r: int,
+    class_token: bool = False,
+    distill_token: bool = False,
+    mode: str = "merge",
+) -> Tuple[Callable, Callable]:
+    """Balanced (even/odd) bipartite matching; input [batch, tokens, channels]; at most 50% of the
+    unprotected tokens are merged.  Returns (merge, unmerge)."""
+    if mode not in ("merge", "random_merge"):
+        raise ValueError(f"bipartite_soft_matching: mode {mode!r} (expected 'merge' or 'random_merge')")
+    plan = _plan(metric, r, class_token, distill_token, random=(mode == "random_merge"))
+    if plan is None:
+        return do_nothing, do_nothing
+    return _make_merge_pair(plan)
+
+
+def _make_merge_pair(plan: _abi.MatchPlan) -> Tuple[Callable, Callable]:
+    unm_idx, src_idx, dst_idx = plan.unm_idx, plan.src_idx, plan.dst_idx
+    r, distill_token = plan.r, plan.distill_token
+
+    def merge(x: torch.Tensor, mode="mean") -> torch.Tensor:
+        assert src_idx.shape[1] == r and dst_idx.shape[1] == r and unm_idx.shape[0] == x.shape[0]
+        assert distill_token == plan.distill_token
+        return _abi.merge(plan, x, mode)
+
+    def unmerge(x: torch.Tensor) -> torch.Tensor:
+        assert src_idx.shape[1] == r and dst_idx.shape[1] == r and unm_idx.shape[0] == x.shape[0]
+        return _abi.unmerge(plan, x)
+
+    merge.plan = plan
+    unmerge.plan = plan
+    return merge, unmerge
+
+
+def bipartite_soft_matching_drop(
+    metric: torch.Tensor,
+    r: int,
+    class_token: bool = False,
+    distill_token: bool = False,
+    mode: str = "drop",
+):
+    """Same matching, but the selected tokens are discarded instead of merged.  Returns ``drop``
+    (a single callable) -- or the (do_nothing, do_nothing) pair when r <= 0, as the reference does."""
+    if mode not in ("drop", "random_drop"):
+        raise ValueError(f"bipartite_soft_matching_drop: mode {mode!r}")
+    plan = _plan(metric, r, class_token, distill_token, random=(mode == "random_drop"))
+    if plan is None:
+        return do_nothing, do_nothing
+    und_idx, src_idx = plan.unm_idx, plan.src_idx
+    r, distill_token = plan.r, plan.distill_token
+
+    def drop(x: torch.Tensor) -> torch.Tensor:
+        assert und_idx.shape[0] == x.shape[0] and src_idx.shape[1] == r
+        assert distill_token == plan.distill_token
+        return _abi.drop(plan, x)
+
+    drop.plan = plan
+    return drop
+
+
+def bipartite_soft_matching_hybrid(
+    metric: torch.Tensor,
+    r: int,
+    class_token: bool = False,
+    distill_token: bool = False,
+    mode: str = "merge",
+    threshold: float = 0.0,
+) -> Tuple[Callable, Callable]:
+    """Merge, but a destination whose incoming edge scores below ``threshold`` loses its own
+    contribution first (merge.py:326)."""
+    if mode not in ("merge", "hybrid", "random_merge"):
+        raise ValueError(f"bipartite_soft_matching_hybrid: mode {mode!r}")
+    plan = _plan(metric, r, class_token, distill_token, random=(mode == "random_merge"), want_node_max=True)
+    if plan is None:
+        return do_nothing, do_nothing
+    with torch.no_grad():
+        plan.edge_keep = _abi.edge_keep(plan, threshold)
+    merge, unmerge = _make_merge_pair(plan)
+    return merge, unmerge
+
+
+def merge_wavg(merge: Callable, x: torch.Tensor, size: Optional[torch.Tensor] = None
+               ) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Size-weighted average merge; returns the merged tensor and the new token sizes.  With a merge
+    made by this package the whole ``x*size -> sum, sum -> x/size`` chain is one kernel launch."""
+    plan = getattr(merge, "plan", None)
+    if plan is not None:
+        return _abi.merge_wavg(plan, x, size)
+    # foreign callables (and do_nothing): the reference's op sequence on the tensors' own device
+    if size is None:
+        size = torch.ones_like(x[..., 0, None])
+    x = merge(x * size, mode="sum")
+    size = merge(size, mode="sum")
+    x = x / size
+    return x, size
+
+
+def merge_source(merge: Callable, x: torch.Tensor, source: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Source tracking: adjacency between the initial tokens and the merged groups."""
+    if source is None:
+        n, t, _ = x.shape
+        source = torch.eye(t, device=x.device)[None, ...].expand(n, t, t)
+    source = merge(source, mode="max")
+    return source
