@@ -707,7 +707,8 @@ extern "C" int tome_match(const void *metric, int dtype, int64_t n, int64_t T, i
         return fail(TOME_EINVAL, "tome_match: problem too large");
     const int64_t re = tome_effective_r(T, r, class_token, distill_token);
     if (re <= 0) return TOME_OK;
-    if (!src_idx || !dst_idx || !unm_idx) return fail(TOME_EINVAL, "tome_match: null index buffer");
+    if (!src_idx || !dst_idx || (!unm_idx && (T + 1) / 2 > re))
+        return fail(TOME_EINVAL, "tome_match: null index buffer");
     if (!workspace || workspace_bytes < tome_match_workspace_bytes(n, T, D))
         return fail(TOME_EWORKSPACE, "tome_match: workspace %zu < %zu bytes", workspace_bytes,
                     tome_match_workspace_bytes(n, T, D));
@@ -764,7 +765,8 @@ extern "C" int tome_match_scores(const float *scores, int64_t n, int64_t T, int6
     if (!scores || n <= 0 || T <= 0) return fail(TOME_EINVAL, "tome_match_scores: bad shape/pointer");
     const int64_t re = tome_effective_r(T, r, class_token, distill_token);
     if (re <= 0) return TOME_OK;
-    if (!src_idx || !dst_idx || !unm_idx) return fail(TOME_EINVAL, "tome_match_scores: null index buffer");
+    if (!src_idx || !dst_idx || (!unm_idx && (T + 1) / 2 > re))
+        return fail(TOME_EINVAL, "tome_match_scores: null index buffer");
     if (!workspace || workspace_bytes < tome_match_workspace_bytes(n, T, 1))
         return fail(TOME_EWORKSPACE, "tome_match_scores: workspace too small");
     if (((uintptr_t)workspace & 255) != 0) return fail(TOME_EINVAL, "tome_match_scores: workspace alignment");
@@ -822,7 +824,8 @@ extern "C" int tome_merge_wavg(const void *x, int x_dtype, const void *size, int
                                const int64_t *unm_idx, int distill_token, const uint8_t *edge_keep, void *x_out,
                                void *size_out, tome_stream_t stream) {
     if (int rc = check_merge_args("tome_merge_wavg", x, n, T, C, r, x_out)) return rc;
-    if (!src_idx || !dst_idx || !unm_idx || !size_out) return fail(TOME_EINVAL, "tome_merge_wavg: null buffer");
+    if (!src_idx || !dst_idx || (!unm_idx && (T + 1) / 2 > r) || !size_out)
+        return fail(TOME_EINVAL, "tome_merge_wavg: null buffer");
     hipStream_t st = (hipStream_t)stream;
 #define WAVG(TX, TS)                                                                                         \
     return launch_merge_rows<TX, TS, OP_WAVG>(x, size, n, T, C, r, src_idx, dst_idx, unm_idx, distill_token, \
@@ -866,7 +869,8 @@ extern "C" int tome_merge(const void *x, int dtype, int64_t n, int64_t T, int64_
                           const int64_t *src_idx, const int64_t *dst_idx, const int64_t *unm_idx, int distill_token,
                           int mode, const uint8_t *edge_keep, void *out, tome_stream_t stream) {
     if (int rc = check_merge_args("tome_merge", x, n, T, C, r, out)) return rc;
-    if (!src_idx || !dst_idx || !unm_idx) return fail(TOME_EINVAL, "tome_merge: null index buffer");
+    if (!src_idx || !dst_idx || (!unm_idx && (T + 1) / 2 > r))
+        return fail(TOME_EINVAL, "tome_merge: null index buffer");
     if (mode < TOME_SUM || mode > TOME_AMIN) return fail(TOME_EINVAL, "tome_merge: mode %d", mode);
     return merge_dtype_dispatch("tome_merge", dtype, mode, x, n, T, C, r, src_idx, dst_idx, unm_idx, distill_token,
                                 edge_keep, out, (hipStream_t)stream);
@@ -875,7 +879,7 @@ extern "C" int tome_merge(const void *x, int dtype, int64_t n, int64_t T, int64_
 extern "C" int tome_drop(const void *x, int dtype, int64_t n, int64_t T, int64_t C, int64_t r,
                          const int64_t *und_idx, int distill_token, void *out, tome_stream_t stream) {
     if (int rc = check_merge_args("tome_drop", x, n, T, C, r, out)) return rc;
-    if (!und_idx) return fail(TOME_EINVAL, "tome_drop: null index buffer");
+    if (!und_idx && (T + 1) / 2 > r) return fail(TOME_EINVAL, "tome_drop: null index buffer");
     return merge_dtype_dispatch("tome_drop", dtype, OP_DROP, x, n, T, C, r, nullptr, nullptr, und_idx, distill_token,
                                 nullptr, out, (hipStream_t)stream);
 }
@@ -899,7 +903,8 @@ extern "C" int tome_unmerge(const void *x, int dtype, int64_t n, int64_t T, int6
                             const int64_t *src_idx, const int64_t *dst_idx, const int64_t *unm_idx, void *out,
                             tome_stream_t stream) {
     if (int rc = check_merge_args("tome_unmerge", x, n, T, C, r, out)) return rc;
-    if (!src_idx || !dst_idx || !unm_idx) return fail(TOME_EINVAL, "tome_unmerge: null index buffer");
+    if (!src_idx || !dst_idx || (!unm_idx && (T + 1) / 2 > r))
+        return fail(TOME_EINVAL, "tome_unmerge: null index buffer");
     hipStream_t st = (hipStream_t)stream;
     switch (dtype) {
     case TOME_F32: return launch_unmerge<float>(x, n, T, C, r, src_idx, dst_idx, unm_idx, out, st);
