@@ -1,0 +1,278 @@
+#!/usr/bin/env python3
+"""Headline benchmark: clips/s of a VideoMAE-B 16x224x224 forward with ToMe r=16 (BASELINE.json
+configs[1]), bf16, synthetic clips resident in HBM, one process per GPU.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A step is one forward of the patched model over this rank's batch of clips (patch embed -> 12 blocks,
+each with the HIP merge path between attention and MLP -> head -> top-1/top-5 counts on device).  Ranks
+are independent replicas on different clips (weak scaling, no data-path collective); one RCCL
+all-reduce of [top1, top5, clips] closes the timed region.  Rank 0 prints ONE JSON line.
+
+Besides the throughput the line carries
+  roofline      the dominant merge-path kernel against its bound (HBM 8 TB/s or fp32-MFMA 157.3 TF/s,
+                /opt/skills/guides/MI355X_MICROARCH.md), from HIP-event timings taken in this run
+  cpu_baseline  the reference's PyTorch-CPU path (restated in oracle/torch_port.py, kind "port") timed
+                on this host's cores on a bounded sample of the same workload
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG_DIR = os.path.join(ROOT, "video-how-do-your-tokens-merge_amd")
+for _p in (ROOT, PKG_DIR):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md, chip-level parameters)
+MFMA_F32_PEAK_TFLOPS = 157.3  # v_mfma_f32_32x32x2_f32 dense peak (same table)
+
+EMBED, HEADS, HEAD_DIM, LAYERS = 768, 12, 64, 12
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=32, help="clips per GPU per step")
+    ap.add_argument("--frames", type=int, default=16)
+    ap.add_argument("--r", type=int, default=16)
+    ap.add_argument("--cpu-clips", type=int, default=2, help="batch of the CPU baseline sample")
+    ap.add_argument("--cpu-iters", type=int, default=4)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    return ap.parse_args()
+
+
+def token_schedule(t0: int, r: int, layers: int):
+    out, t = [], t0
+    for _ in range(layers):
+        re = max(0, min(r, t // 2))
+        out.append((t, re))
+        t -= re
+    return out
+
+
+def measure_kernels(batch: int, t0: int, r: int, dev, reps: int = 10):
+    """HIP-event timing of the merge-path kernels at the 12 layer shapes of this workload, on the stream
+    they are launched on (torch's current stream).  Returns per-kernel totals over one forward's launches."""
+    from tome import _abi
+    L = _abi.lib()
+    sched = [(t, re) for t, re in token_schedule(t0, r, LAYERS) if re > 0]
+    g = torch.Generator(device=dev).manual_seed(7)
+    stats = {
+        "k_unit_rows": {"ms": 0.0, "bytes": 0, "flops": 0, "launches": 0},
+        "k_scores_rowmax": {"ms": 0.0, "bytes": 0, "flops": 0, "launches": 0},
+        "k_rank_select": {"ms": 0.0, "bytes": 0, "flops": 0, "launches": 0},
+        "k_merge_rows": {"ms": 0.0, "bytes": 0, "flops": 0, "launches": 0},
+    }
+    st = torch.cuda.current_stream(dev).cuda_stream
+    for t, re in sched:
+        metric = torch.randn(batch, t, HEAD_DIM, device=dev, generator=g).bfloat16()
+        x = torch.randn(batch, t, EMBED, device=dev, generator=g).bfloat16()
+        size = torch.randint(1, 4, (batch, t, 1), device=dev, generator=g).bfloat16()
+        # --- matching: per-stage events recorded inside tome_match
+        _abi.profile_enable(True)
+        acc = [0.0, 0.0, 0.0]
+        plan = None
+        for i in range(reps + 2):
+            plan = _abi.match(metric, re)
+            ms = _abi.profile_read()
+            if i >= 2:
+                acc = [a + b for a, b in zip(acc, ms)]
+        _abi.profile_enable(False)
+        t1, t2 = (t + 1) // 2, t // 2
+        for name, ms in zip(("k_unit_rows", "k_scores_rowmax", "k_rank_select"), acc):
+            stats[name]["ms"] += ms / reps
+            stats[name]["launches"] += 1
+        stats["k_unit_rows"]["bytes"] += batch * t * HEAD_DIM * (2 + 4)      # read bf16 keys, write fp32 units
+        stats["k_scores_rowmax"]["flops"] += batch * 2 * t1 * t2 * HEAD_DIM
+        stats["k_scores_rowmax"]["bytes"] += batch * t * HEAD_DIM * 4
+        stats["k_rank_select"]["bytes"] += batch * (t1 * 8 + t1 * 8)
+        # --- merge: one kernel per call, timed over back-to-back launches with preallocated outputs
+        x_out = torch.empty(batch, t - re, EMBED, device=dev, dtype=torch.bfloat16)
+        s_out = torch.empty(batch, t - re, 1, device=dev, dtype=torch.bfloat16)
+
+        def launch():
+            rc = L.tome_merge_wavg(x.data_ptr(), 1, size.data_ptr(), 1, batch, t, EMBED, re, plan.src_idx.data_ptr(),
+                                   plan.dst_idx.data_ptr(), plan.unm_idx.data_ptr(), 0, None, x_out.data_ptr(),
+                                   s_out.data_ptr(), st)
+            assert rc == 0
+        for _ in range(2):
+            launch()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            launch()
+        e1.record()
+        e1.synchronize()
+        stats["k_merge_rows"]["ms"] += e0.elapsed_time(e1) / reps
+        stats["k_merge_rows"]["launches"] += 1
+        # read x and size once, write x' and size' once (bf16 tokens, bf16 sizes here)
+        stats["k_merge_rows"]["bytes"] += batch * (t * EMBED * 2 + t * 2 + (t - re) * EMBED * 2 + (t - re) * 2)
+    return stats
+
+
+def roofline_of(stats):
+    """Roofline object of the kernel that takes the most device time per forward."""
+    name = max(stats, key=lambda k: stats[k]["ms"])
+    s = stats[name]
+    sec = s["ms"] / 1e3
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get(name)
+        except Exception:
+            traffic = None
+    if name == "k_scores_rowmax":
+        achieved = s["flops"] / sec / 1e12
+        return {"kernel": name, "bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_F32_PEAK_TFLOPS,
+                "unit": "TFLOP/s", "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4), "traffic": traffic,
+                "launches_per_step": s["launches"], "avg_launch_us": round(s["ms"] * 1e3 / s["launches"], 2)}
+    achieved = s["bytes"] / sec / 1e9
+    return {"kernel": name, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "launches_per_step": s["launches"],
+            "avg_launch_us": round(s["ms"] * 1e3 / s["launches"], 2)}
+
+
+def cpu_baseline(frames: int, r: int, clips: int, iters: int):
+    """The reference's PyTorch-CPU path (fp32) on a bounded sample: `iters` forwards of `clips` clips."""
+    from hosts.videomae import videomae_base
+    from oracle import torch_port
+    torch.manual_seed(0)
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    host = videomae_base(num_frames=frames).eval()
+    x = torch.rand(clips, 3, frames, 224, 224)
+    torch_port.videomae_forward(host, x, r)  # warm-up
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        torch_port.videomae_forward(host, x, r)
+    dt = time.perf_counter() - t0
+    return {"value": round(clips * iters / dt, 3), "unit": "clips/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{iters} forwards x {clips} clips, fp32, torch {torch.__version__} CPU, "
+                      f"oracle/torch_port.py (op sequence of tome/merge.py + tome/patch/videomae.py), {dt:.1f}s"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N>1 must be launched through torch.distributed.run (one rank per GPU)")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU path in the product)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)  # "nccl" is RCCL on ROCm
+
+    import tome
+    from tome import _abi
+    from hosts.videomae import videomae_base
+    _abi.lib()  # fail loudly before timing anything if the HIP extension is missing
+
+    torch.manual_seed(0)
+    model = videomae_base(num_frames=args.frames).to(dev).to(torch.bfloat16).eval()
+    tome.patch.videomae(model, prop_attn=False)
+    model.r = args.r
+    t0_tokens = model.model.patch_embed.num_patches
+
+    B = args.batch
+    gen = torch.Generator(device=dev).manual_seed(1000 + rank)
+    clips = torch.rand(B, 3, args.frames, 224, 224, device=dev, generator=gen).to(torch.bfloat16)
+    labels = torch.randint(0, 400, (B,), device=dev, generator=gen)
+    counts = torch.zeros(3, dtype=torch.int64, device=dev)  # top1, top5, clips
+
+    def step():
+        logits = model([clips])
+        top5 = logits.float().topk(5, dim=1).indices
+        hit = top5 == labels[:, None]
+        counts[0] += hit[:, 0].sum()
+        counts[1] += hit.any(dim=1).sum()
+        counts[2] += B
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            step()
+        counts.zero_()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t_start = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        if world > 1:
+            dist.all_reduce(counts)  # the one collective: top-1 / top-5 / clip counts over xGMI
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        elapsed = time.perf_counter() - t_start
+    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    elapsed = float(el.item())
+    total_clips = int(counts[2].item())
+    assert total_clips == B * args.steps * world, (total_clips, B, args.steps, world)
+
+    out = None
+    if rank == 0:
+        out = {
+            "metric": "clips/sec at r=16, VideoMAE-B 16x224x224 (forward with ToMe merge, merge indices bit-exact)",
+            "value": round(total_clips / elapsed, 2),
+            "unit": "clips/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "bf16",
+            "data": "synthetic",
+            "config": {
+                "workload": f"VideoMAE-B random-init, synthetic {args.frames}x224x224 clips, r={args.r}, bf16 "
+                            f"(BASELINE.json configs[1])",
+                "clips_per_gpu_per_step": B, "tokens": t0_tokens, "r": args.r,
+                "tokens_after_12_layers": token_schedule(t0_tokens, args.r, LAYERS)[-1][0]
+                - token_schedule(t0_tokens, args.r, LAYERS)[-1][1],
+                "parallelism": f"dp{world}: independent replicas, one RCCL all-reduce of [top1, top5, clips]",
+            },
+            "top1": int(counts[0].item()), "top5": int(counts[1].item()),
+        }
+        if not args.no_roofline:
+            with torch.no_grad():
+                stats = measure_kernels(B, t0_tokens, args.r, dev)
+            out["roofline"] = roofline_of(stats)
+            out["merge_path_kernels"] = {
+                k: {"ms_per_step": round(v["ms"], 4), "launches": v["launches"],
+                    "GB/s": round(v["bytes"] / (v["ms"] / 1e3) / 1e9, 1) if v["ms"] > 0 else None,
+                    "TFLOP/s": round(v["flops"] / (v["ms"] / 1e3) / 1e12, 2) if v["flops"] else None}
+                for k, v in stats.items()}
+            out["merge_path_ms_per_step"] = round(sum(v["ms"] for v in stats.values()), 4)
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.frames, args.r, args.cpu_clips, args.cpu_iters)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

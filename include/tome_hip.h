@@ -116,6 +116,15 @@ int tome_unmerge(const void *x, int dtype, int64_t n, int64_t T, int64_t C, int6
                  const int64_t *src_idx, const int64_t *dst_idx, const int64_t *unm_idx, void *out,
                  tome_stream_t stream);
 
+/*
+ * Measurement aid (bench.py): when enabled on the calling thread, tome_match records HIP events between
+ * its kernels on the caller's stream; tome_profile_read waits for the last profiled call and returns the
+ * milliseconds of its stages {unit vectors, similarity+row max, rank+select}.  Events are created by
+ * tome_profile_enable(1), never inside a launch path.  No reference counterpart.
+ */
+int tome_profile_enable(int on);
+int tome_profile_read(float *stage_ms, int max_stages);
+
 #ifdef __cplusplus
 }
 #endif

@@ -650,6 +650,43 @@ extern "C" int64_t tome_effective_r(int64_t T, int64_t r, int class_token, int d
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// Optional per-stage timing of tome_match (bench.py's roofline figures): events are created when
+// profiling is switched on, never inside a launch path.
+#define PROF_EVENTS 4
+static thread_local struct {
+    bool on = false;
+    bool valid = false;
+    hipEvent_t ev[PROF_EVENTS];
+} g_prof;
+
+static inline void prof_mark(int i, hipStream_t st) {
+    if (g_prof.on) (void)hipEventRecord(g_prof.ev[i], st);
+}
+
+extern "C" int tome_profile_enable(int on) {
+    if (on && !g_prof.on) {
+        for (int i = 0; i < PROF_EVENTS; ++i)
+            if (hipEventCreate(&g_prof.ev[i]) != hipSuccess) return fail(TOME_ELAUNCH, "hipEventCreate failed");
+        g_prof.on = true;
+        g_prof.valid = false;
+    } else if (!on && g_prof.on) {
+        for (int i = 0; i < PROF_EVENTS; ++i) (void)hipEventDestroy(g_prof.ev[i]);
+        g_prof.on = false;
+        g_prof.valid = false;
+    }
+    return TOME_OK;
+}
+
+extern "C" int tome_profile_read(float *stage_ms, int max_stages) {
+    if (!g_prof.on || !g_prof.valid || !stage_ms) return fail(TOME_EINVAL, "tome_profile_read: no profiled call");
+    if (hipEventSynchronize(g_prof.ev[PROF_EVENTS - 1]) != hipSuccess)
+        return fail(TOME_ELAUNCH, "tome_profile_read: event synchronize failed");
+    for (int i = 0; i + 1 < PROF_EVENTS && i < max_stages; ++i)
+        if (hipEventElapsedTime(&stage_ms[i], g_prof.ev[i], g_prof.ev[i + 1]) != hipSuccess)
+            return fail(TOME_ELAUNCH, "tome_profile_read: elapsed time failed");
+    return TOME_OK;
+}
+
 struct MatchWs {
     float *unitA, *unitB, *node_max;
     int *node_idx, *rank;
@@ -719,6 +756,7 @@ extern "C" int tome_match(const void *metric, int dtype, int64_t n, int64_t T, i
     const int Dp = (int)((D + 63) / 64 * 64);
 
     // 1. unit vectors
+    prof_mark(0, st);
     int tok = (int)(65536 / ((D + 1) * sizeof(float)));
     if (tok > 64) tok = 64;
     if (tok < 1) return fail(TOME_EINVAL, "tome_match: D=%lld too wide", (long long)D);
@@ -740,6 +778,7 @@ extern "C" int tome_match(const void *metric, int dtype, int64_t n, int64_t T, i
     default: return fail(TOME_EINVAL, "tome_match: dtype %d", dtype);
     }
     if (int rc = check_launch("k_unit_rows")) return rc;
+    prof_mark(1, st);
 
     // 2. similarity + row max/argmax
     const int tiles = (T1 + TILE_ROWS - 1) / TILE_ROWS;
@@ -753,9 +792,13 @@ extern "C" int tome_match(const void *metric, int dtype, int64_t n, int64_t T, i
         hipLaunchKernelGGL(k_scores_rowmax<false>, dim3(nb2), dim3(64 * W), 0, st, w.unitA, w.unitB, (int)n, T1,
                            T2, Dp, wgpg, class_token, distill_token, w.node_max, w.node_idx);
     if (int rc = check_launch("k_scores_rowmax")) return rc;
+    prof_mark(2, st);
 
     // 3. rank + select
-    return launch_select(w, n, T, re, class_token, distill_token, src_idx, dst_idx, unm_idx, node_max, row_map, st);
+    int rc = launch_select(w, n, T, re, class_token, distill_token, src_idx, dst_idx, unm_idx, node_max, row_map, st);
+    prof_mark(3, st);
+    g_prof.valid = g_prof.on && rc == TOME_OK;
+    return rc;
 }
 
 extern "C" int tome_match_scores(const float *scores, int64_t n, int64_t T, int64_t r, int class_token,

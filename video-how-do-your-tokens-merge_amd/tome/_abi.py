@@ -17,6 +17,7 @@ LIB_PATH = os.environ.get("TOME_HIP_LIB", os.path.join(_PKG, "lib", "libtome_hip
 SYMBOLS = (
     "tome_abi_version", "tome_last_error", "tome_effective_r", "tome_match_workspace_bytes", "tome_match",
     "tome_match_scores", "tome_edge_keep", "tome_merge_wavg", "tome_merge", "tome_drop", "tome_unmerge",
+    "tome_profile_enable", "tome_profile_read",
 )
 
 ABI_VERSION = 1
@@ -64,6 +65,10 @@ def lib() -> ctypes.CDLL:
     L.tome_drop.argtypes = [vp, i32, i64, i64, i64, i64, vp, i32, vp, vp]
     L.tome_unmerge.restype = i32
     L.tome_unmerge.argtypes = [vp, i32, i64, i64, i64, i64, vp, vp, vp, vp, vp]
+    L.tome_profile_enable.restype = i32
+    L.tome_profile_enable.argtypes = [i32]
+    L.tome_profile_read.restype = i32
+    L.tome_profile_read.argtypes = [vp, i32]
     if L.tome_abi_version() != ABI_VERSION:
         raise TomeHipError(f"libtome_hip.so ABI {L.tome_abi_version()} != expected {ABI_VERSION}")
     _lib = L
@@ -274,3 +279,15 @@ def unmerge(plan: MatchPlan, x: torch.Tensor) -> torch.Tensor:
                                 plan.dst_idx.data_ptr(), plan.unm_idx.data_ptr(), out.data_ptr(), _stream(x.device))
     _check(rc, "tome_unmerge")
     return out
+
+
+def profile_enable(on: bool) -> None:
+    _check(lib().tome_profile_enable(int(on)), "tome_profile_enable")
+
+
+def profile_read():
+    """Milliseconds of the stages {unit vectors, similarity + row max, rank + select} of the last
+    tome_match issued from this thread while profiling was on (waits for it to finish)."""
+    buf = (ctypes.c_float * 3)()
+    _check(lib().tome_profile_read(buf, 3), "tome_profile_read")
+    return [float(v) for v in buf]

@@ -1,0 +1,120 @@
+"""Shared machinery of the four model patches (reference: tome/patch/{videomae,timesformer,motionformer,
+vivit}.py).  The reference imports the concrete slowfast / HF classes and swaps ``__class__``; here the
+ToMe subclasses are created on the fly from whatever class the module already has, so the same patch
+works on the reference's own model objects and on the host models of this repository
+(``video-how-do-your-tokens-merge_amd/hosts``) without importing slowfast.
+"""
+from __future__ import annotations
+
+from typing import Callable, Dict, Tuple
+
+import torch
+
+from ..merge import (bipartite_soft_matching, bipartite_soft_matching_drop, bipartite_soft_matching_hybrid,
+                     merge_source, merge_wavg)
+from ..utils import parse_r
+
+_SUBCLASSES: Dict[Tuple[type, str], type] = {}
+
+
+def swizzle(module: torch.nn.Module, tag: str, methods: dict) -> None:
+    """Give ``module`` a subclass of its current class carrying ``methods`` (the reference assigns
+    ``module.__class__ = ToMeBlock``; same effect, no dependency on the concrete base class)."""
+    base = module.__class__
+    if getattr(base, "_tome_tag", None) == tag:
+        return
+    key = (base, tag)
+    sub = _SUBCLASSES.get(key)
+    if sub is None:
+        sub = type(tag, (base,), dict(methods, _tome_tag=tag))
+        _SUBCLASSES[key] = sub
+    module.__class__ = sub
+
+
+def has_tag(module, tag: str) -> bool:
+    return getattr(module.__class__, "_tome_tag", None) == tag
+
+
+def new_tome_info(trace_source, prop_attn, mode, head_aggregation, threshold, verbose, class_token) -> dict:
+    """The shared per-model state dict (videomae.py:181-193)."""
+    return {
+        "r": 0,
+        "size": None,
+        "source": None,
+        "trace_source": trace_source,
+        "prop_attn": prop_attn,
+        "verbose": verbose,
+        "class_token": class_token,
+        "distill_token": False,
+        "mode": mode,
+        "head_aggregation": head_aggregation,
+        "threshold": threshold,
+    }
+
+
+def wrap_model_forward(model_wrapper: torch.nn.Module, blocks_of: Callable) -> None:
+    """make_tome_class (videomae.py:160-169): every forward re-reads ``self.r`` into a per-layer list and
+    clears size/source."""
+    base = model_wrapper.__class__
+    if getattr(base, "_tome_tag", None) == "ToMeVisionTransformer":
+        return
+
+    def forward(self, *args, **kwdargs):
+        self._tome_info["r"] = parse_r(len(blocks_of(self)), self.r)
+        self._tome_info["size"] = None
+        self._tome_info["source"] = None
+        return super(sub, self).forward(*args, **kwdargs)
+
+    sub = type("ToMeVisionTransformer", (base,), {"forward": forward, "_tome_tag": "ToMeVisionTransformer"})
+    model_wrapper.__class__ = sub
+
+
+def pick_reduction(mode: str, merge_fn, drop_fn, hybrid_fn):
+    if mode in ("merge", "random_merge"):
+        return merge_fn
+    if mode in ("drop", "random_drop"):
+        return drop_fn
+    if mode in ("hybrid",):
+        return hybrid_fn
+    raise ValueError(f"unknown ToMe mode {mode!r}")
+
+
+# ---- the reduction step on an already grouped [n, T, C] token tensor ---------------------------------
+def reduce_merge(metric, x, info, r):
+    merge, _ = bipartite_soft_matching(metric, r, info["class_token"], info["distill_token"], info["mode"])
+    if info["trace_source"]:
+        info["source"] = merge_source(merge, x, info["source"])
+    before = x.size(1)
+    x, info["size"] = merge_wavg(merge, x, info["size"])
+    if info["verbose"]:
+        print(f"Merged {before} to {x.size(1)} tokens")
+    return x
+
+
+def reduce_drop(metric, x, info, r):
+    drop = bipartite_soft_matching_drop(metric, r, info["class_token"], info["distill_token"], info["mode"])
+    if isinstance(drop, tuple):  # clamped r == 0: the reference returns the do_nothing pair here
+        drop = drop[0]
+    if info["trace_source"]:
+        if info["source"] is None:
+            n, t, _ = x.shape
+            info["source"] = torch.eye(t, device=x.device)[None, ...].expand(n, t, t)
+        info["source"] = drop(info["source"])
+    before = x.size(1)
+    x = drop(x)
+    info["size"] = torch.ones((x.size(0), x.size(1), 1), device=x.device)
+    if info["verbose"]:
+        print(f"Dropped {before} to {x.size(1)} tokens")
+    return x
+
+
+def reduce_hybrid(metric, x, info, r):
+    merge, _ = bipartite_soft_matching_hybrid(metric, r, info["class_token"], info["distill_token"], info["mode"],
+                                              info["threshold"])
+    if info["trace_source"]:
+        info["source"] = merge_source(merge, x, info["source"])
+    before = x.size(1)
+    x, info["size"] = merge_wavg(merge, x, info["size"])
+    if info["verbose"]:
+        print(f"Merged {before} to {x.size(1)} tokens")
+    return x
