@@ -23,7 +23,9 @@
  *
  * Arithmetic contract (shared bit-for-bit with the HIP kernels):
  *   - every input is first converted to fp32 (exact for bf16/fp16);
- *   - squared norm of a token: ss = 0; for k ascending: ss = fmaf(v[k], v[k], ss);
+ *   - squared norm of a token: channels are taken in blocks of 8 (one 16-byte bf16 lane load);
+ *     part_b = fma chain over the block's channels in ascending order starting from 0;
+ *     ss = ((part_0 + part_1) + part_2) + ... in ascending block order (fp32 adds);
  *     norm = sqrtf(ss) (correctly rounded); unit[k] = v[k] / norm (IEEE division,
  *     no epsilon: a zero token gives NaN like merge.py:51);
  *   - similarity: acc = 0; for k ascending: acc = fmaf(a[k], b[k], acc)  -- this is
@@ -62,7 +64,11 @@ static void unit_rows(const float *m, int64_t rows, int64_t D, float *out) {
     for (int64_t t = 0; t < rows; ++t) {
         const float *v = m + t * D;
         float ss = 0.0f;
-        for (int64_t k = 0; k < D; ++k) ss = fmaf(v[k], v[k], ss);
+        for (int64_t k0 = 0; k0 < D; k0 += 8) { /* blocks of 8 channels, see the contract above */
+            float part = 0.0f;
+            for (int64_t k = k0; k < D && k < k0 + 8; ++k) part = fmaf(v[k], v[k], part);
+            ss = ss + part;
+        }
         float nrm = sqrtf(ss);
         for (int64_t k = 0; k < D; ++k) out[t * D + k] = v[k] / nrm;
     }

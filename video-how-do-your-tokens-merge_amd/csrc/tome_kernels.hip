@@ -72,198 +72,279 @@ __device__ __forceinline__ void store_pack(T *p, const float (&in)[VEC]) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_unit_rows: merge.py:51-52.  One thread per token runs the sequential fma chain of the squared
-// norm (the contract's order); the division and the scatter into the two fragment-ordered sets
-// are spread over the whole workgroup.
-//   unitA [n][T1][Dp], unitB [n][T2][Dp]; a row holds its even-k elements in the first Dp/2 floats
-//   and its odd-k elements in the second Dp/2 -- lane half h of v_mfma_f32_32x32x2_f32 supplies
-//   k = 2s+h at step s, so each lane reads one contiguous run.  Dp = D rounded up to 64, zero filled.
+// Workspace layout of the unit vectors ("fragment-major tiles").  Both sets (A = even tokens, B = odd
+// tokens) are cut into tiles of 32 rows; a tile is stored exactly as the 64 lanes of
+// v_mfma_f32_32x32x2_f32 consume it, so every operand fetch is one fully coalesced 1-KiB
+// global_load_dwordx4 per 4 k-pairs:
+//     float4 index inside a group = ((tile * nchunk + c) * 8 + q) * 64 + lane
+//     lane = (row & 31) + 32*h holds unit[row][k = 2*s + h] for the 4 pairs s = 32*c + 4*q + {0,1,2,3}
+// (lane half h supplies k = 2s+h at MFMA step s).  Dp = D rounded up to 64 (nchunk = Dp/64), the
+// padding channels are written as zeros; rows past the end of a set are never written nor used.
 // ------------------------------------------------------------------------------------------------
-template <typename T>
-__global__ __launch_bounds__(256) void k_unit_rows(const T *__restrict__ metric, int64_t stride_n,
-                                                   int64_t stride_t, int n, int T_, int D, int Dp,
-                                                   int tok_per_wg, float *__restrict__ unitA,
-                                                   float *__restrict__ unitB) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int ld = D + 1;
-    float *tile = lds;                      // [tok_per_wg][D+1]
-    float *nrm = lds + (size_t)tok_per_wg * ld;  // [tok_per_wg]
-    const int tid = threadIdx.x;
-    const int64_t tok0 = (int64_t)blockIdx.x * tok_per_wg;
-    const int64_t ntok = (int64_t)n * T_;
-    const int T1 = (T_ + 1) >> 1, T2 = T_ >> 1;
+__device__ __forceinline__ int64_t frag_index(int tile, int nchunk, int c, int q, int lane) {
+    return (((int64_t)tile * nchunk + c) * 8 + q) * 64 + lane;
+}
 
-    for (int lt = tid >> 6; lt < tok_per_wg; lt += 4) {
-        int64_t tok = tok0 + lt;
-        if (tok >= ntok) break;
-        int64_t g = tok / T_;
-        int t = (int)(tok - g * T_);
-        const T *row = metric + g * stride_n + (int64_t)t * stride_t;
-        for (int k = tid & 63; k < D; k += 64) tile[lt * ld + k] = to_f32(row[k]);
+template <typename T> struct Load8;  // 8 consecutive channels of one token -> fp32
+template <> struct Load8<float> {
+    static __device__ __forceinline__ void run(const float *p, float (&v)[8]) {
+        f32x4 a = *reinterpret_cast<const f32x4 *>(p), b = *reinterpret_cast<const f32x4 *>(p + 4);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
     }
-    __syncthreads();
-    if (tid < tok_per_wg && tok0 + tid < ntok) {
-        const float *v = tile + tid * ld;
-        float ss = 0.0f;
-        for (int k = 0; k < D; ++k) ss = __fmaf_rn(v[k], v[k], ss);
-        nrm[tid] = __fsqrt_rn(ss);
-    }
-    __syncthreads();
-    const int half = Dp >> 1;
-    for (int lt = tid >> 6; lt < tok_per_wg; lt += 4) {
-        int64_t tok = tok0 + lt;
-        if (tok >= ntok) break;
-        int64_t g = tok / T_;
-        int t = (int)(tok - g * T_);
-        float *dst = (t & 1) ? unitB + ((int64_t)g * T2 + (t >> 1)) * Dp
-                             : unitA + ((int64_t)g * T1 + (t >> 1)) * Dp;
-        float nr = nrm[lt];
-        for (int k = tid & 63; k < Dp; k += 64) {
-            float u = (k < D) ? __fdiv_rn(tile[lt * ld + k], nr) : 0.0f;
-            dst[(k & 1) * half + (k >> 1)] = u;
+};
+template <> struct Load8<bf16_t> {
+    static __device__ __forceinline__ void run(const bf16_t *p, float (&v)[8]) { load_pack<bf16_t, 8>(p, v); }
+};
+template <> struct Load8<f16_t> {
+    static __device__ __forceinline__ void run(const f16_t *p, float (&v)[8]) { load_pack<f16_t, 8>(p, v); }
+};
+
+// ------------------------------------------------------------------------------------------------
+// k_unit_rows: merge.py:51-52.  Eight lanes per token, 16-byte (bf16/fp16) or 2x16-byte (fp32) loads;
+// lane b of a token owns the channel blocks b, b+8, ... (8 channels each).  Squared norm in the
+// contract's order: fma chain inside a block, blocks added in ascending order (the partials travel
+// between the 8 lanes by shuffles).  Each lane then divides its channels and writes two float4 per
+// block: the even channels to lane slot (row&31), the odd ones to slot (row&31)+32 of the tile.
+// NCH = Dp/64 is a template parameter so that the per-lane partials stay in registers.
+// ------------------------------------------------------------------------------------------------
+template <typename T, int NCH>
+__global__ __launch_bounds__(256) void k_unit_rows(const T *__restrict__ metric, int64_t stride_n,
+                                                   int64_t stride_t, int n, int T_, int D,
+                                                   float *__restrict__ unitA, float *__restrict__ unitB,
+                                                   int64_t groupA_f4, int64_t groupB_f4) {
+    const int lane = threadIdx.x & 63;
+    const int b8 = lane & 7;
+    const int64_t tok = ((int64_t)blockIdx.x * (blockDim.x >> 3)) + (threadIdx.x >> 3);
+    const int64_t ntok = (int64_t)n * T_;
+    const bool live = tok < ntok;
+    const int64_t tk = live ? tok : ntok - 1;
+    const int g = (int)(tk / T_);
+    const int t = (int)(tk - (int64_t)g * T_);
+    const T *row = metric + (int64_t)g * stride_n + (int64_t)t * stride_t;
+    const int nblk = D >> 3;  // D % 8 == 0 on this path
+
+    float v[NCH][8];
+    float part[NCH];
+#pragma unroll
+    for (int it = 0; it < NCH; ++it) {
+        const int b = b8 + 8 * it;
+        part[it] = 0.0f;
+        if (b < nblk) {
+            Load8<T>::run(row + 8 * b, v[it]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) part[it] = __fmaf_rn(v[it][e], v[it][e], part[it]);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[it][e] = 0.0f;
         }
+    }
+    float ss = 0.0f;
+    const int base = lane & ~7;
+#pragma unroll
+    for (int it = 0; it < NCH; ++it) {
+#pragma unroll
+        for (int l = 0; l < 8; ++l) {
+            const float p = __shfl(part[it], base + l);
+            if (l + 8 * it < nblk) ss = __fadd_rn(ss, p);
+        }
+    }
+    const float nr = __builtin_sqrtf(ss);
+    if (!live) return;
+    const int rowi = t >> 1;
+    f32x4 *dst = reinterpret_cast<f32x4 *>((t & 1) ? unitB : unitA) + (int64_t)g * ((t & 1) ? groupB_f4 : groupA_f4);
+    const int tile = rowi >> 5, slot = rowi & 31;
+#pragma unroll
+    for (int it = 0; it < NCH; ++it) {
+        const int b = b8 + 8 * it;
+        f32x4 ev, od;
+        if (b < nblk) {
+            ev.x = __fdiv_rn(v[it][0], nr); od.x = __fdiv_rn(v[it][1], nr);
+            ev.y = __fdiv_rn(v[it][2], nr); od.y = __fdiv_rn(v[it][3], nr);
+            ev.z = __fdiv_rn(v[it][4], nr); od.z = __fdiv_rn(v[it][5], nr);
+            ev.w = __fdiv_rn(v[it][6], nr); od.w = __fdiv_rn(v[it][7], nr);
+        } else {
+            ev.x = ev.y = ev.z = ev.w = 0.0f;
+            od = ev;
+        }
+        // block b -> pairs s = 4b..4b+3 -> chunk c = b/8 = it, q = b%8 = b8
+        const int64_t f = frag_index(tile, NCH, it, b8, slot);
+        dst[f] = ev;
+        dst[f + 32] = od;
+    }
+}
+
+// Any D (also D % 8 != 0, unaligned rows): one thread per token, scalar accesses, same arithmetic order.
+template <typename T>
+__global__ __launch_bounds__(256) void k_unit_rows_generic(const T *__restrict__ metric, int64_t stride_n,
+                                                           int64_t stride_t, int n, int T_, int D, int Dp,
+                                                           float *__restrict__ unitA, float *__restrict__ unitB,
+                                                           int64_t groupA_f4, int64_t groupB_f4) {
+    const int64_t tok = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tok >= (int64_t)n * T_) return;
+    const int g = (int)(tok / T_);
+    const int t = (int)(tok - (int64_t)g * T_);
+    const T *row = metric + (int64_t)g * stride_n + (int64_t)t * stride_t;
+    float ss = 0.0f;
+    for (int k0 = 0; k0 < D; k0 += 8) {
+        float part = 0.0f;
+        for (int k = k0; k < D && k < k0 + 8; ++k) {
+            const float v = to_f32(row[k]);
+            part = __fmaf_rn(v, v, part);
+        }
+        ss = __fadd_rn(ss, part);
+    }
+    const float nr = __builtin_sqrtf(ss);
+    const int rowi = t >> 1, tile = rowi >> 5, slot = rowi & 31, nchunk = Dp >> 6;
+    float *dst = ((t & 1) ? unitB : unitA) + 4 * (int64_t)g * ((t & 1) ? groupB_f4 : groupA_f4);
+    for (int k = 0; k < Dp; ++k) {
+        const float u = (k < D) ? __fdiv_rn(to_f32(row[k]), nr) : 0.0f;
+        const int s = k >> 1, h = k & 1;
+        const int64_t f = frag_index(tile, nchunk, s >> 5, (s & 31) >> 2, slot + 32 * h);
+        dst[4 * f + (s & 3)] = u;
     }
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_scores_rowmax: merge.py:53,59-64 without the score matrix.
-//   workgroup = W waves (W in {1,2,4,8}); wave w owns 32 A rows (columns of the transposed tile),
-//   every wave of the group streams the same B rows through LDS (double buffered, one barrier per
-//   32-row tile).  S^T tile = Bhat_tile (MFMA "A" operand, from LDS) x Ahat^T (MFMA "B" operand,
-//   registers): accumulator register v of lane l holds S[i = l&31][j = (v&3)+8(v>>2)+4(l>>5)], so
-//   the max over j is a per-lane running max, combined across the two lane halves once at the end.
-//   v_mfma_f32_32x32x2_f32 adds k = 2s then k = 2s+1 to the accumulator: a k-ordered fma chain.
+// k_scores_rowmax: merge.py:53,59-64 without the score matrix, without LDS staging.
+//   One workgroup per (group, A tile of 32 rows); its WJ waves split the B tiles between them, so a
+//   workgroup's waves never read the same operand and every wave streams its B tiles straight from
+//   L2 into registers (fragment-major layout: 8 coalesced 1-KiB loads per 32 rows x 64 channels),
+//   one tile ahead of the MFMAs.  S^T tile = Bhat_tile (MFMA "A" operand) x Ahat^T (MFMA "B"
+//   operand, loaded once): accumulator register v of lane l holds
+//   S[i = l&31][j = 32*jt + (v&3) + 8*(v>>2) + 4*(l>>5)], so the max over j is a per-lane running
+//   max, merged across the two lane halves and then across the WJ waves (ascending j, strict >, so
+//   the first maximal column wins) through 2 KiB of LDS at the very end.
+//   v_mfma_f32_32x32x2_f32 adds k = 2s then k = 2s+1 to the accumulator: the contract's fma chain.
 // ------------------------------------------------------------------------------------------------
 #define TILE_ROWS 32
-#define LDS_ROW 68 /* floats: 64 + 4 pad -> 272-byte rows, conflict-free ds_read_b128 */
+#define MAX_WJ 8
 
 template <bool ONE_CHUNK>
-__global__ __launch_bounds__(512) void k_scores_rowmax(const float *__restrict__ unitA,
-                                                       const float *__restrict__ unitB, int n, int T1,
-                                                       int T2, int Dp, int wg_per_group, int class_token,
-                                                       int distill_token, float *__restrict__ node_max,
-                                                       int *__restrict__ node_idx) {
-    __shared__ __attribute__((aligned(16))) float lds[2][TILE_ROWS * LDS_ROW];
+__global__ __launch_bounds__(64 * MAX_WJ) void k_scores_rowmax(const f32x4 *__restrict__ unitA,
+                                                               const f32x4 *__restrict__ unitB, int n, int T1,
+                                                               int T2, int nchunk, int ntA, int ntB,
+                                                               int64_t groupA_f4, int64_t groupB_f4,
+                                                               int class_token, int distill_token,
+                                                               float *__restrict__ node_max,
+                                                               int *__restrict__ node_idx) {
+    __shared__ float s_best[MAX_WJ][32];
+    __shared__ int s_idx[MAX_WJ][32];
     // XCD-aware block -> (group, tile) map: blocks b and b+8 share an XCD (round-robin dispatch), so
-    // all workgroups of one group -- which stream the same B rows -- are given ids congruent mod 8
-    // and find those rows in their XCD's L2.  Placement only affects speed.
+    // all workgroups of one group -- which stream the same B tiles -- get ids congruent mod 8 and
+    // find those tiles in their XCD's L2.  Placement only affects speed.
     const int L = blockIdx.x;
-    const int xcd = L & 7, q = L >> 3;
-    const int g = (q / wg_per_group) * 8 + xcd;
-    const int wg_in_group = q % wg_per_group;
+    const int xcd = L & 7, qq = L >> 3;
+    const int g = (qq / ntA) * 8 + xcd;
+    const int ti = qq % ntA;
     if (g >= n) return;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int W = blockDim.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int WJ = blockDim.x >> 6;
     const int col = lane & 31, h = lane >> 5;
-    const int i0 = (wg_in_group * W + wave) * TILE_ROWS;
-    const int i = i0 + col;
-    const int nchunk = Dp >> 6;
-    const int halfD = Dp >> 1;
-    const int ntile = (T2 + TILE_ROWS - 1) / TILE_ROWS;
-    const int nstep = ntile * nchunk;
+    const int i = ti * TILE_ROWS + col;
+    // this wave's B tiles: [jt0, jt1), balanced split of ntB over WJ waves
+    const int jt0 = (int)(((int64_t)ntB * wave) / WJ), jt1 = (int)(((int64_t)ntB * (wave + 1)) / WJ);
 
-    const float *arow = unitA + ((int64_t)g * T1 + (i < T1 ? i : T1 - 1)) * Dp + h * halfD;
-    const float *bbase = unitB + (int64_t)g * T2 * Dp;
+    const f32x4 *atile = unitA + (int64_t)g * groupA_f4 + frag_index(ti, nchunk, 0, 0, lane);
+    const f32x4 *bgrp = unitB + (int64_t)g * groupB_f4 + lane;
 
-    float af[32];
+    f32x4 af[8];
     if (ONE_CHUNK) {
 #pragma unroll
-        for (int qd = 0; qd < 8; ++qd) {
-            f32x4 v = *reinterpret_cast<const f32x4 *>(arow + 4 * qd);
-            af[4 * qd + 0] = v.x; af[4 * qd + 1] = v.y; af[4 * qd + 2] = v.z; af[4 * qd + 3] = v.w;
-        }
+        for (int q = 0; q < 8; ++q) af[q] = atile[q * 64];
     }
-
-    // staging: a (tile, chunk) step is 32 rows x 64 floats = 512 float4; blockDim.x threads move
-    // 512 / blockDim.x float4 each (W=8 -> 1, W=4 -> 2, W=2 -> 4, W=1 -> 8).
-    const int per_thread = 512 / blockDim.x;
-    f32x4 stage[8];
-    auto stage_load = [&](int step) {
-        const int jt = step / nchunk, c = step - jt * nchunk;
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            if (u < per_thread) {
-                int f = u * blockDim.x + tid;       // float4 index inside the step: row*16 + q4
-                int row = f >> 4, q4 = f & 15;      // q4 0..7 even-k half, 8..15 odd-k half
-                int j = jt * TILE_ROWS + row;
-                if (j >= T2) j = T2 - 1;
-                const float *src = bbase + (int64_t)j * Dp + (q4 >> 3) * halfD + c * 32 + (q4 & 7) * 4;
-                stage[u] = *reinterpret_cast<const f32x4 *>(src);
-            }
-        }
-    };
-    auto stage_write = [&](int buf) {
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            if (u < per_thread) {
-                int f = u * blockDim.x + tid;
-                int row = f >> 4, q4 = f & 15;
-                *reinterpret_cast<f32x4 *>(&lds[buf][row * LDS_ROW + q4 * 4]) = stage[u];
-            }
-        }
-    };
-
     float best = -INFINITY;
     int bidx = 0;
+    const int nstep = (jt1 - jt0) * nchunk;
+    f32x4 cur[8], nxt[8];
+    if (nstep > 0) {
+        const f32x4 *p = bgrp + frag_index(jt0, nchunk, 0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) cur[q] = p[q * 64];
+    }
     f32x16 acc;
-
-    stage_load(0);
-    stage_write(0);
-    __syncthreads();
+    int jt = jt0, c = 0;
     for (int step = 0; step < nstep; ++step) {
-        const int jt = step / nchunk, c = step - jt * nchunk;
-        if (step + 1 < nstep) stage_load(step + 1);
+        if (step + 1 < nstep) {  // steps are consecutive (tile, chunk) blocks of 512 float4
+            const f32x4 *p = bgrp + frag_index(jt0, nchunk, 0, 0, 0) + (int64_t)(step + 1) * 512;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) nxt[q] = p[q * 64];
+        }
         if (!ONE_CHUNK) {
 #pragma unroll
-            for (int qd = 0; qd < 8; ++qd) {
-                f32x4 v = *reinterpret_cast<const f32x4 *>(arow + c * 32 + 4 * qd);
-                af[4 * qd + 0] = v.x; af[4 * qd + 1] = v.y; af[4 * qd + 2] = v.z; af[4 * qd + 3] = v.w;
-            }
+            for (int q = 0; q < 8; ++q) af[q] = atile[(c * 8 + q) * 64];
         }
         if (c == 0) {
 #pragma unroll
             for (int v = 0; v < 16; ++v) acc[v] = 0.0f;
         }
-        const float *brow = &lds[step & 1][col * LDS_ROW + h * 32];
-        float bf[32];
 #pragma unroll
-        for (int qd = 0; qd < 8; ++qd) {
-            f32x4 v = *reinterpret_cast<const f32x4 *>(brow + 4 * qd);
-            bf[4 * qd + 0] = v.x; bf[4 * qd + 1] = v.y; bf[4 * qd + 2] = v.z; bf[4 * qd + 3] = v.w;
+        for (int q = 0; q < 8; ++q) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[q].x, af[q].x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[q].y, af[q].y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[q].z, af[q].z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[q].w, af[q].w, acc, 0, 0, 0);
         }
-#pragma unroll
-        for (int s = 0; s < 32; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[s], af[s], acc, 0, 0, 0);
         if (c == nchunk - 1) {
             const int jbase = jt * TILE_ROWS + 4 * h;
+            const bool edge = (jt == 0 && distill_token) || ((jt + 1) * TILE_ROWS > T2);
+            if (!edge) {
 #pragma unroll
-            for (int v = 0; v < 16; ++v) {
-                const int j = jbase + (v & 3) + 8 * (v >> 2);
-                const float sc = acc[v];
-                bool ok = (j < T2) && !(distill_token && j == 0);
-                if (ok && sc > best) {
-                    best = sc;
-                    bidx = j;
+                for (int v = 0; v < 16; ++v) {
+                    const float sc = acc[v];
+                    const bool up = sc > best;
+                    best = up ? sc : best;
+                    bidx = up ? jbase + (v & 3) + 8 * (v >> 2) : bidx;
+                }
+            } else {
+#pragma unroll
+                for (int v = 0; v < 16; ++v) {
+                    const int j = jbase + (v & 3) + 8 * (v >> 2);
+                    const float sc = acc[v];
+                    const bool up = (j < T2) && !(distill_token && j == 0) && (sc > best);
+                    best = up ? sc : best;
+                    bidx = up ? j : bidx;
                 }
             }
         }
-        if (step + 1 < nstep) stage_write((step + 1) & 1);
-        __syncthreads();
+        if (++c == nchunk) {
+            c = 0;
+            ++jt;
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) cur[q] = nxt[q];
     }
     // the two lane halves hold the same A row, disjoint B rows: keep the larger, first index on ties
-    float ob = __shfl_xor(best, 32);
-    int oi = __shfl_xor(bidx, 32);
-    if (ob > best || (ob == best && oi < bidx)) {
-        best = ob;
-        bidx = oi;
+    {
+        const float ob = __shfl_xor(best, 32);
+        const int oi = __shfl_xor(bidx, 32);
+        if (ob > best || (ob == best && oi < bidx)) {
+            best = ob;
+            bidx = oi;
+        }
     }
-    if (class_token && i == 0) {  // merge.py:59-60: the class token's row is all -inf
-        best = -INFINITY;
-        bidx = 0;
+    if (h == 0) {
+        s_best[wave][col] = best;
+        s_idx[wave][col] = bidx;
     }
-    if (h == 0 && i < T1) {
-        node_max[(int64_t)g * T1 + i] = best;
-        node_idx[(int64_t)g * T1 + i] = bidx;
+    __syncthreads();
+    if (wave == 0 && h == 0 && i < T1) {
+        float fb = s_best[0][col];
+        int fi = s_idx[0][col];
+        for (int w = 1; w < WJ; ++w) {  // ascending j ranges: strict > keeps the first maximum
+            const float ob = s_best[w][col];
+            if (ob > fb) {
+                fb = ob;
+                fi = s_idx[w][col];
+            }
+        }
+        if (class_token && i == 0) {  // merge.py:59-60: the class token's row is all -inf
+            fb = -INFINITY;
+            fi = 0;
+        }
+        node_max[(int64_t)g * T1 + i] = fb;
+        node_idx[(int64_t)g * T1 + i] = fi;
     }
 }
 
@@ -319,8 +400,9 @@ __global__ __launch_bounds__(256) void k_rowmax_given(const float *__restrict__ 
 
 // ------------------------------------------------------------------------------------------------
 // k_rank_select: merge.py:65-69.  rank(i) = #{j : key_j before key_i}, keys descending, NaN first,
-// -0 == +0, equal keys in ascending row order.  Each thread ranks one row against all T1 keys held
-// in LDS (broadcast reads); the rank IS the position in edge_idx, so src/dst/unm are written directly.
+// -0 == +0, equal keys in ascending row order.  The order is made total by a 64-bit key
+// (sortable score << 32 | ~row); a workgroup ranks 64 rows, 4 lanes per row each counting a quarter of
+// the keys held in LDS; the rank IS the position in edge_idx, so src/dst/unm are written directly.
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t sort_key(float f) {
     if (f != f) return 0xFFFFFFFFu;
@@ -342,25 +424,27 @@ __global__ __launch_bounds__(256) void k_rank_select(const float *__restrict__ n
                                                      int64_t *__restrict__ dst_idx,
                                                      int64_t *__restrict__ unm_idx, int *__restrict__ rank_out,
                                                      int *__restrict__ row_map) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t keys[];
+    extern __shared__ __attribute__((aligned(16))) unsigned long long keys[];
     const int g = blockIdx.y;
-    const int T1p = (T1 + 3) & ~3;
+    const int quarter = (((T1 + 3) >> 2) + 1) & ~1;  // keys per lane, even (two keys per 16-byte read)
+    const int T1p = quarter * 4;
     const float *nm = node_max + (int64_t)g * T1;
-    for (int j = threadIdx.x; j < T1p; j += blockDim.x) keys[j] = (j < T1) ? sort_key(nm[j]) : 0u;
+    for (int j = threadIdx.x; j < T1p; j += blockDim.x)
+        keys[j] = (j < T1) ? (((unsigned long long)sort_key(nm[j]) << 32) | (0xFFFFFFFFu - (uint32_t)j)) : 0ull;
     __syncthreads();
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= T1) return;
-    const uint32_t ki = keys[i];
+    const int part = threadIdx.x & 3;
+    const int i = blockIdx.x * 64 + (threadIdx.x >> 2);
+    const unsigned long long ki = keys[i < T1 ? i : T1 - 1];
     int cnt = 0;
-    const uint4 *k4 = reinterpret_cast<const uint4 *>(keys);
-    for (int j4 = 0; j4 < (T1p >> 2); ++j4) {
-        uint4 k = k4[j4];
-        const int j = j4 << 2;
-        cnt += (k.x > ki) || (k.x == ki && (j + 0) < i);
-        cnt += (k.y > ki) || (k.y == ki && (j + 1) < i);
-        cnt += (k.z > ki) || (k.z == ki && (j + 2) < i);
-        cnt += (k.w > ki) || (k.w == ki && (j + 3) < i);
+    const ulonglong2 *k2 = reinterpret_cast<const ulonglong2 *>(keys + part * quarter);
+    for (int j2 = 0; j2 < (quarter >> 1); ++j2) {
+        const ulonglong2 k = k2[j2];
+        cnt += (k.x > ki) ? 1 : 0;
+        cnt += (k.y > ki) ? 1 : 0;
     }
+    cnt += __shfl_xor(cnt, 1);
+    cnt += __shfl_xor(cnt, 2);
+    if (part != 0 || i >= T1) return;
     const int U = T1 - r;
     const int64_t gi = (int64_t)g * T1 + i;
     if (rank_out) rank_out[gi] = cnt;
@@ -690,17 +774,23 @@ extern "C" int tome_profile_read(float *stage_ms, int max_stages) {
 struct MatchWs {
     float *unitA, *unitB, *node_max;
     int *node_idx, *rank;
+    int ntA, ntB, nchunk;
+    int64_t groupA_f4, groupB_f4;  // float4 per group of each unit set
     size_t bytes;
 };
 
 static MatchWs carve(void *base, int64_t n, int64_t T, int64_t D) {
     const int64_t T1 = (T + 1) / 2, T2 = T / 2;
-    const int64_t Dp = (D + 63) / 64 * 64;
-    size_t off = 0;
     MatchWs w;
+    w.nchunk = (int)((D + 63) / 64);
+    w.ntA = (int)((T1 + TILE_ROWS - 1) / TILE_ROWS);
+    w.ntB = (int)((T2 + TILE_ROWS - 1) / TILE_ROWS);
+    w.groupA_f4 = (int64_t)w.ntA * w.nchunk * 512;
+    w.groupB_f4 = (int64_t)w.ntB * w.nchunk * 512;
+    size_t off = 0;
     char *b = (char *)base;
-    w.unitA = (float *)(b + off); off = align_up(off + sizeof(float) * (size_t)(n * T1 * Dp), 256);
-    w.unitB = (float *)(b + off); off = align_up(off + sizeof(float) * (size_t)(n * T2 * Dp), 256);
+    w.unitA = (float *)(b + off); off = align_up(off + 16 * (size_t)(n * w.groupA_f4), 256);
+    w.unitB = (float *)(b + off); off = align_up(off + 16 * (size_t)(n * w.groupB_f4), 256);
     w.node_max = (float *)(b + off); off = align_up(off + sizeof(float) * (size_t)(n * T1), 256);
     w.node_idx = (int *)(b + off); off = align_up(off + sizeof(int) * (size_t)(n * T1), 256);
     w.rank = (int *)(b + off); off = align_up(off + sizeof(int) * (size_t)(n * T1), 256);
@@ -717,8 +807,9 @@ static int launch_select(const MatchWs &w, int64_t n, int64_t T, int64_t re, int
                          int distill_token, int64_t *src_idx, int64_t *dst_idx, int64_t *unm_idx,
                          float *node_max, int32_t *row_map, hipStream_t st) {
     const int T1 = (int)((T + 1) / 2);
-    dim3 grid((T1 + 255) / 256, (unsigned)n);
-    const size_t lds = sizeof(uint32_t) * (size_t)((T1 + 3) & ~3);
+    dim3 grid((T1 + 63) / 64, (unsigned)n);
+    const int quarter = (((T1 + 3) >> 2) + 1) & ~1;
+    const size_t lds = sizeof(unsigned long long) * (size_t)(4 * quarter);
     hipLaunchKernelGGL(k_rank_select, grid, dim3(256), lds, st, w.node_max, w.node_idx, (int)n, T1, (int)re,
                        class_token, distill_token, src_idx, dst_idx, unm_idx, w.rank, row_map);
     if (int rc = check_launch("k_rank_select")) return rc;
@@ -753,44 +844,70 @@ extern "C" int tome_match(const void *metric, int dtype, int64_t n, int64_t T, i
     hipStream_t st = (hipStream_t)stream;
     const MatchWs w = carve(workspace, n, T, D);
     const int T1 = (int)((T + 1) / 2), T2 = (int)(T / 2);
-    const int Dp = (int)((D + 63) / 64 * 64);
 
     // 1. unit vectors
     prof_mark(0, st);
-    int tok = (int)(65536 / ((D + 1) * sizeof(float)));
-    if (tok > 64) tok = 64;
-    if (tok < 1) return fail(TOME_EINVAL, "tome_match: D=%lld too wide", (long long)D);
-    const size_t lds1 = sizeof(float) * ((size_t)tok * (D + 1) + tok);
-    const unsigned nb1 = (unsigned)((n * T + tok - 1) / tok);
+    const size_t es = dtype == TOME_F32 ? 4 : 2;
+    const bool fast = (D % 8 == 0) && (((uintptr_t)metric) % 16 == 0) && ((stride_n * es) % 16 == 0) &&
+                      ((stride_t * es) % 16 == 0);
+    bool launched = false;
+#define UNIT_FAST(TY, NCH)                                                                                    \
+    hipLaunchKernelGGL((k_unit_rows<TY, NCH>), dim3((unsigned)((n * T + 31) / 32)), dim3(256), 0, st,          \
+                       (const TY *)metric, stride_n, stride_t, (int)n, (int)T, (int)D, w.unitA, w.unitB,       \
+                       w.groupA_f4, w.groupB_f4);                                                              \
+    launched = true
+#define UNIT_NCH(TY)                                       \
+    switch (w.nchunk) {                                    \
+    case 1: UNIT_FAST(TY, 1); break;                       \
+    case 2: UNIT_FAST(TY, 2); break;                       \
+    case 3: UNIT_FAST(TY, 3); break;                       \
+    case 4: UNIT_FAST(TY, 4); break;                       \
+    case 6: UNIT_FAST(TY, 6); break;                       \
+    case 8: UNIT_FAST(TY, 8); break;                       \
+    case 12: UNIT_FAST(TY, 12); break;                     \
+    case 16: UNIT_FAST(TY, 16); break;                     \
+    default: break;                                        \
+    }
+#define UNIT_GENERIC(TY)                                                                                       \
+    hipLaunchKernelGGL((k_unit_rows_generic<TY>), dim3((unsigned)((n * T + 255) / 256)), dim3(256), 0, st,      \
+                       (const TY *)metric, stride_n, stride_t, (int)n, (int)T, (int)D, w.nchunk * 64, w.unitA,  \
+                       w.unitB, w.groupA_f4, w.groupB_f4)
     switch (dtype) {
     case TOME_F32:
-        hipLaunchKernelGGL(k_unit_rows<float>, dim3(nb1), dim3(256), lds1, st, (const float *)metric, stride_n,
-                           stride_t, (int)n, (int)T, (int)D, Dp, tok, w.unitA, w.unitB);
+        if (fast) { UNIT_NCH(float) }
+        if (!launched) UNIT_GENERIC(float);
         break;
     case TOME_BF16:
-        hipLaunchKernelGGL(k_unit_rows<bf16_t>, dim3(nb1), dim3(256), lds1, st, (const bf16_t *)metric, stride_n,
-                           stride_t, (int)n, (int)T, (int)D, Dp, tok, w.unitA, w.unitB);
+        if (fast) { UNIT_NCH(bf16_t) }
+        if (!launched) UNIT_GENERIC(bf16_t);
         break;
     case TOME_F16:
-        hipLaunchKernelGGL(k_unit_rows<f16_t>, dim3(nb1), dim3(256), lds1, st, (const f16_t *)metric, stride_n,
-                           stride_t, (int)n, (int)T, (int)D, Dp, tok, w.unitA, w.unitB);
+        if (fast) { UNIT_NCH(f16_t) }
+        if (!launched) UNIT_GENERIC(f16_t);
         break;
     default: return fail(TOME_EINVAL, "tome_match: dtype %d", dtype);
     }
+#undef UNIT_FAST
+#undef UNIT_NCH
+#undef UNIT_GENERIC
     if (int rc = check_launch("k_unit_rows")) return rc;
     prof_mark(1, st);
 
-    // 2. similarity + row max/argmax
-    const int tiles = (T1 + TILE_ROWS - 1) / TILE_ROWS;
-    int W = tiles >= 4 ? 4 : (tiles >= 2 ? 2 : 1);
-    const int wgpg = (tiles + W - 1) / W;
-    const unsigned nb2 = (unsigned)(((n + 7) / 8) * 8 * wgpg);
-    if (Dp == 64)
-        hipLaunchKernelGGL(k_scores_rowmax<true>, dim3(nb2), dim3(64 * W), 0, st, w.unitA, w.unitB, (int)n, T1, T2,
-                           Dp, wgpg, class_token, distill_token, w.node_max, w.node_idx);
+    // 2. similarity + row max/argmax: one workgroup per (group, A tile), WJ waves split the B tiles so
+    // that the launch has about three waves per SIMD (1024 SIMDs) whatever the batch
+    int WJ = (int)((3072 + n * w.ntA - 1) / (n * w.ntA));
+    if (WJ > MAX_WJ) WJ = MAX_WJ;
+    if (WJ > w.ntB) WJ = w.ntB;
+    if (WJ < 1) WJ = 1;
+    const unsigned nb2 = (unsigned)(((n + 7) / 8) * 8 * w.ntA);
+    if (w.nchunk == 1)
+        hipLaunchKernelGGL(k_scores_rowmax<true>, dim3(nb2), dim3(64 * WJ), 0, st, (const f32x4 *)w.unitA,
+                           (const f32x4 *)w.unitB, (int)n, T1, T2, w.nchunk, w.ntA, w.ntB, w.groupA_f4, w.groupB_f4,
+                           class_token, distill_token, w.node_max, w.node_idx);
     else
-        hipLaunchKernelGGL(k_scores_rowmax<false>, dim3(nb2), dim3(64 * W), 0, st, w.unitA, w.unitB, (int)n, T1,
-                           T2, Dp, wgpg, class_token, distill_token, w.node_max, w.node_idx);
+        hipLaunchKernelGGL(k_scores_rowmax<false>, dim3(nb2), dim3(64 * WJ), 0, st, (const f32x4 *)w.unitA,
+                           (const f32x4 *)w.unitB, (int)n, T1, T2, w.nchunk, w.ntA, w.ntB, w.groupA_f4, w.groupB_f4,
+                           class_token, distill_token, w.node_max, w.node_idx);
     if (int rc = check_launch("k_scores_rowmax")) return rc;
     prof_mark(2, st);
 
