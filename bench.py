@@ -78,10 +78,13 @@ def measure_kernels(batch: int, t0: int, r: int, dev, reps: int = 10):
         "k_merge_rows": {"ms": 0.0, "bytes": 0, "flops": 0, "launches": 0},
     }
     st = torch.cuda.current_stream(dev).cuda_stream
+    # the tokens and their sizes evolve through the 12 layers exactly as in a forward (most sizes stay 1,
+    # merged tokens carry 2, 3, ...); the keys of every layer are fresh random bf16 tensors
+    x = torch.randn(batch, t0, EMBED, device=dev, generator=g).bfloat16()
+    size = None
     for t, re in sched:
+        assert x.shape[1] == t
         metric = torch.randn(batch, t, HEAD_DIM, device=dev, generator=g).bfloat16()
-        x = torch.randn(batch, t, EMBED, device=dev, generator=g).bfloat16()
-        size = torch.randint(1, 4, (batch, t, 1), device=dev, generator=g).bfloat16()
         # --- matching: per-stage events recorded inside tome_match
         _abi.profile_enable(True)
         acc = [0.0, 0.0, 0.0]
@@ -103,9 +106,10 @@ def measure_kernels(batch: int, t0: int, r: int, dev, reps: int = 10):
         # --- merge: one kernel per call, timed over back-to-back launches with preallocated outputs
         x_out = torch.empty(batch, t - re, EMBED, device=dev, dtype=torch.bfloat16)
         s_out = torch.empty(batch, t - re, 1, device=dev, dtype=torch.bfloat16)
+        sp = None if size is None else size.data_ptr()
 
         def launch():
-            rc = L.tome_merge_wavg(x.data_ptr(), 1, size.data_ptr(), 1, batch, t, EMBED, re, plan.src_idx.data_ptr(),
+            rc = L.tome_merge_wavg(x.data_ptr(), 1, sp, 1, batch, t, EMBED, re, plan.src_idx.data_ptr(),
                                    plan.dst_idx.data_ptr(), plan.unm_idx.data_ptr(), 0, None, x_out.data_ptr(),
                                    s_out.data_ptr(), st)
             assert rc == 0
@@ -121,6 +125,7 @@ def measure_kernels(batch: int, t0: int, r: int, dev, reps: int = 10):
         stats["k_merge_rows"]["launches"] += 1
         # read x and size once, write x' and size' once (bf16 tokens, bf16 sizes here)
         stats["k_merge_rows"]["bytes"] += batch * (t * EMBED * 2 + t * 2 + (t - re) * EMBED * 2 + (t - re) * 2)
+        x, size = x_out, s_out
     return stats
 
 

@@ -17,6 +17,7 @@
 #include <stdarg.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "../../include/tome_hip.h"
@@ -205,146 +206,125 @@ __global__ __launch_bounds__(256) void k_unit_rows_generic(const T *__restrict__
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_scores_rowmax: merge.py:53,59-64 without the score matrix, without LDS staging.
-//   One workgroup per (group, A tile of 32 rows); its WJ waves split the B tiles between them, so a
-//   workgroup's waves never read the same operand and every wave streams its B tiles straight from
-//   L2 into registers (fragment-major layout: 8 coalesced 1-KiB loads per 32 rows x 64 channels),
-//   one tile ahead of the MFMAs.  S^T tile = Bhat_tile (MFMA "A" operand) x Ahat^T (MFMA "B"
-//   operand, loaded once): accumulator register v of lane l holds
+// k_scores_rowmax: merge.py:53,59-64 without the score matrix, without LDS.
+//   One WAVE per work item (group, A tile of 32 rows, j-part): single-wave workgroups, so the
+//   dispatcher balances thousands of small items over the 1024 SIMDs and no barrier exists.  The
+//   wave keeps its 32 A rows in registers (MFMA "B" operand) and streams its share of the B tiles
+//   straight from L2 (fragment-major layout: 8 coalesced 1-KiB loads per 32 rows x 64 channels),
+//   one tile ahead of the MFMAs, ping-ponging two register buffers.
+//   S^T tile = Bhat_tile (MFMA "A" operand) x Ahat^T: accumulator register v of lane l holds
 //   S[i = l&31][j = 32*jt + (v&3) + 8*(v>>2) + 4*(l>>5)], so the max over j is a per-lane running
-//   max, merged across the two lane halves and then across the WJ waves (ascending j, strict >, so
-//   the first maximal column wins) through 2 KiB of LDS at the very end.
+//   max, merged across the two lane halves at the end.  Each j-part writes its (max, first argmax)
+//   to part_max/part_idx [n][WJ][T1]; k_rank_select folds the parts in ascending j order.
 //   v_mfma_f32_32x32x2_f32 adds k = 2s then k = 2s+1 to the accumulator: the contract's fma chain.
 // ------------------------------------------------------------------------------------------------
 #define TILE_ROWS 32
 #define MAX_WJ 8
 
+struct RowBest {
+    float best;
+    int idx;
+};
+
+__device__ __forceinline__ void fold_tile(const f32x16 &acc, RowBest &rb, int jt, int h, int T2, int distill_token) {
+    const int jbase = jt * TILE_ROWS + 4 * h;
+    const bool edge = (jt == 0 && distill_token) || ((jt + 1) * TILE_ROWS > T2);
+    if (!edge) {
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            const float sc = acc[v];
+            const bool up = sc > rb.best;
+            rb.best = up ? sc : rb.best;
+            rb.idx = up ? jbase + (v & 3) + 8 * (v >> 2) : rb.idx;
+        }
+    } else {
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            const int j = jbase + (v & 3) + 8 * (v >> 2);
+            const float sc = acc[v];
+            const bool up = (j < T2) && !(distill_token && j == 0) && (sc > rb.best);
+            rb.best = up ? sc : rb.best;
+            rb.idx = up ? j : rb.idx;
+        }
+    }
+}
+
 template <bool ONE_CHUNK>
-__global__ __launch_bounds__(64 * MAX_WJ) void k_scores_rowmax(const f32x4 *__restrict__ unitA,
-                                                               const f32x4 *__restrict__ unitB, int n, int T1,
-                                                               int T2, int nchunk, int ntA, int ntB,
-                                                               int64_t groupA_f4, int64_t groupB_f4,
-                                                               int class_token, int distill_token,
-                                                               float *__restrict__ node_max,
-                                                               int *__restrict__ node_idx) {
-    __shared__ float s_best[MAX_WJ][32];
-    __shared__ int s_idx[MAX_WJ][32];
-    // XCD-aware block -> (group, tile) map: blocks b and b+8 share an XCD (round-robin dispatch), so
-    // all workgroups of one group -- which stream the same B tiles -- get ids congruent mod 8 and
+__global__ __launch_bounds__(64) void k_scores_rowmax(const f32x4 *__restrict__ unitA,
+                                                      const f32x4 *__restrict__ unitB, int n, int T1, int T2,
+                                                      int nchunk, int ntA, int ntB, int WJ, int64_t groupA_f4,
+                                                      int64_t groupB_f4, int distill_token,
+                                                      float *__restrict__ part_max, int *__restrict__ part_idx) {
+    // XCD-aware block -> (group, tile, part) map: blocks b and b+8 share an XCD (round-robin dispatch),
+    // so all work items of one group -- which stream the same B tiles -- get ids congruent mod 8 and
     // find those tiles in their XCD's L2.  Placement only affects speed.
     const int L = blockIdx.x;
     const int xcd = L & 7, qq = L >> 3;
-    const int g = (qq / ntA) * 8 + xcd;
-    const int ti = qq % ntA;
+    const int per_group = ntA * WJ;
+    const int g = (qq / per_group) * 8 + xcd;
     if (g >= n) return;
+    const int item = qq % per_group;
+    const int ti = item / WJ, part = item % WJ;
 
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int WJ = blockDim.x >> 6;
+    const int lane = threadIdx.x;
     const int col = lane & 31, h = lane >> 5;
     const int i = ti * TILE_ROWS + col;
-    // this wave's B tiles: [jt0, jt1), balanced split of ntB over WJ waves
-    const int jt0 = (int)(((int64_t)ntB * wave) / WJ), jt1 = (int)(((int64_t)ntB * (wave + 1)) / WJ);
+    // this wave's B tiles: [jt0, jt1), balanced split of ntB over WJ parts
+    const int jt0 = (int)(((int64_t)ntB * part) / WJ), jt1 = (int)(((int64_t)ntB * (part + 1)) / WJ);
 
     const f32x4 *atile = unitA + (int64_t)g * groupA_f4 + frag_index(ti, nchunk, 0, 0, lane);
-    const f32x4 *bgrp = unitB + (int64_t)g * groupB_f4 + lane;
+    const f32x4 *bstream = unitB + (int64_t)g * groupB_f4 + frag_index(jt0, nchunk, 0, 0, lane);
 
-    f32x4 af[8];
-    if (ONE_CHUNK) {
-#pragma unroll
-        for (int q = 0; q < 8; ++q) af[q] = atile[q * 64];
-    }
-    float best = -INFINITY;
-    int bidx = 0;
-    const int nstep = (jt1 - jt0) * nchunk;
-    f32x4 cur[8], nxt[8];
+    RowBest rb = {-INFINITY, 0};
+    const int nstep = (jt1 - jt0) * nchunk;  // consecutive (tile, chunk) blocks of 512 float4
     if (nstep > 0) {
-        const f32x4 *p = bgrp + frag_index(jt0, nchunk, 0, 0, 0);
-#pragma unroll
-        for (int q = 0; q < 8; ++q) cur[q] = p[q * 64];
-    }
-    f32x16 acc;
-    int jt = jt0, c = 0;
-    for (int step = 0; step < nstep; ++step) {
-        if (step + 1 < nstep) {  // steps are consecutive (tile, chunk) blocks of 512 float4
-            const f32x4 *p = bgrp + frag_index(jt0, nchunk, 0, 0, 0) + (int64_t)(step + 1) * 512;
-#pragma unroll
-            for (int q = 0; q < 8; ++q) nxt[q] = p[q * 64];
-        }
-        if (!ONE_CHUNK) {
-#pragma unroll
-            for (int q = 0; q < 8; ++q) af[q] = atile[(c * 8 + q) * 64];
-        }
-        if (c == 0) {
-#pragma unroll
-            for (int v = 0; v < 16; ++v) acc[v] = 0.0f;
-        }
+        f32x4 af[8], bt[8];
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[q].x, af[q].x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[q].y, af[q].y, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[q].z, af[q].z, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[q].w, af[q].w, acc, 0, 0, 0);
+            af[q] = atile[q * 64];
+            bt[q] = bstream[q * 64];
         }
-        if (c == nchunk - 1) {
-            const int jbase = jt * TILE_ROWS + 4 * h;
-            const bool edge = (jt == 0 && distill_token) || ((jt + 1) * TILE_ROWS > T2);
-            if (!edge) {
+        f32x16 acc;
+        int jt = jt0, c = 0;
+        for (int step = 0; step < nstep; ++step) {
+            // operands of the NEXT step replace each float4 right after its last use (single register
+            // buffer, each load has 7/8 of a step to land); the last step re-reads its own block
+            const int nx = step + 1 < nstep ? step + 1 : step;
+            const f32x4 *nb = bstream + (int64_t)nx * 512;
+            const int cn = (c + 1 == nchunk) ? 0 : c + 1;
+            if (c == 0) {
 #pragma unroll
-                for (int v = 0; v < 16; ++v) {
-                    const float sc = acc[v];
-                    const bool up = sc > best;
-                    best = up ? sc : best;
-                    bidx = up ? jbase + (v & 3) + 8 * (v >> 2) : bidx;
-                }
-            } else {
-#pragma unroll
-                for (int v = 0; v < 16; ++v) {
-                    const int j = jbase + (v & 3) + 8 * (v >> 2);
-                    const float sc = acc[v];
-                    const bool up = (j < T2) && !(distill_token && j == 0) && (sc > best);
-                    best = up ? sc : best;
-                    bidx = up ? j : bidx;
-                }
+                for (int v = 0; v < 16; ++v) acc[v] = 0.0f;
             }
-        }
-        if (++c == nchunk) {
-            c = 0;
-            ++jt;
-        }
 #pragma unroll
-        for (int q = 0; q < 8; ++q) cur[q] = nxt[q];
+            for (int q = 0; q < 8; ++q) {
+                const f32x4 b = bt[q], a = af[q];
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.x, a.x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.y, a.y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.z, a.z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.w, a.w, acc, 0, 0, 0);
+                bt[q] = nb[q * 64];
+                if (!ONE_CHUNK) af[q] = atile[(cn * 8 + q) * 64];
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (c == nchunk - 1) fold_tile(acc, rb, jt, h, T2, distill_token);
+            c = cn;
+            jt += (cn == 0);
+        }
     }
     // the two lane halves hold the same A row, disjoint B rows: keep the larger, first index on ties
     {
-        const float ob = __shfl_xor(best, 32);
-        const int oi = __shfl_xor(bidx, 32);
-        if (ob > best || (ob == best && oi < bidx)) {
-            best = ob;
-            bidx = oi;
+        const float ob = __shfl_xor(rb.best, 32);
+        const int oi = __shfl_xor(rb.idx, 32);
+        if (ob > rb.best || (ob == rb.best && oi < rb.idx)) {
+            rb.best = ob;
+            rb.idx = oi;
         }
     }
-    if (h == 0) {
-        s_best[wave][col] = best;
-        s_idx[wave][col] = bidx;
-    }
-    __syncthreads();
-    if (wave == 0 && h == 0 && i < T1) {
-        float fb = s_best[0][col];
-        int fi = s_idx[0][col];
-        for (int w = 1; w < WJ; ++w) {  // ascending j ranges: strict > keeps the first maximum
-            const float ob = s_best[w][col];
-            if (ob > fb) {
-                fb = ob;
-                fi = s_idx[w][col];
-            }
-        }
-        if (class_token && i == 0) {  // merge.py:59-60: the class token's row is all -inf
-            fb = -INFINITY;
-            fi = 0;
-        }
-        node_max[(int64_t)g * T1 + i] = fb;
-        node_idx[(int64_t)g * T1 + i] = fi;
+    if (h == 0 && i < T1) {
+        const int64_t o = ((int64_t)g * WJ + part) * T1 + i;
+        part_max[o] = rb.best;
+        part_idx[o] = rb.idx;
     }
 }
 
@@ -417,23 +397,37 @@ __device__ __forceinline__ int out_row_dst(int j, int U, int distill) {
     return j == 0 ? 1 : U + j;
 }
 
-__global__ __launch_bounds__(256) void k_rank_select(const float *__restrict__ node_max,
-                                                     const int *__restrict__ node_idx, int n, int T1, int r,
-                                                     int class_token, int distill_token,
+__global__ __launch_bounds__(256) void k_rank_select(const float *__restrict__ part_max,
+                                                     const int *__restrict__ part_idx, int nparts, int n, int T1,
+                                                     int r, int class_token, int distill_token,
                                                      int64_t *__restrict__ src_idx,
                                                      int64_t *__restrict__ dst_idx,
-                                                     int64_t *__restrict__ unm_idx, int *__restrict__ rank_out,
-                                                     int *__restrict__ row_map) {
+                                                     int64_t *__restrict__ unm_idx, float *__restrict__ node_max,
+                                                     int *__restrict__ rank_out, int *__restrict__ row_map) {
     extern __shared__ __attribute__((aligned(16))) unsigned long long keys[];
     const int g = blockIdx.y;
     const int quarter = (((T1 + 3) >> 2) + 1) & ~1;  // keys per lane, even (two keys per 16-byte read)
     const int T1p = quarter * 4;
-    const float *nm = node_max + (int64_t)g * T1;
-    for (int j = threadIdx.x; j < T1p; j += blockDim.x)
-        keys[j] = (j < T1) ? (((unsigned long long)sort_key(nm[j]) << 32) | (0xFFFFFFFFu - (uint32_t)j)) : 0ull;
+    const float *pm = part_max + (int64_t)g * nparts * T1;
+    const int *pi = part_idx + (int64_t)g * nparts * T1;
+    const int i = blockIdx.x * 64 + (threadIdx.x >> 2);
+    for (int j = threadIdx.x; j < T1p; j += blockDim.x) {
+        unsigned long long key = 0ull;
+        if (j < T1) {
+            // fold the j-parts of k_scores_rowmax in ascending order; strict > keeps the first maximum
+            float pv[MAX_WJ];
+#pragma unroll
+            for (int p = 0; p < MAX_WJ; ++p) pv[p] = (p < nparts) ? pm[(int64_t)p * T1 + j] : -INFINITY;
+            float best = pv[0];
+#pragma unroll
+            for (int p = 1; p < MAX_WJ; ++p) best = pv[p] > best ? pv[p] : best;
+            if (class_token && j == 0) best = -INFINITY;  // merge.py:59-60: the class token's row is -inf
+            key = ((unsigned long long)sort_key(best) << 32) | (0xFFFFFFFFu - (uint32_t)j);
+        }
+        keys[j] = key;
+    }
     __syncthreads();
     const int part = threadIdx.x & 3;
-    const int i = blockIdx.x * 64 + (threadIdx.x >> 2);
     const unsigned long long ki = keys[i < T1 ? i : T1 - 1];
     int cnt = 0;
     const ulonglong2 *k2 = reinterpret_cast<const ulonglong2 *>(keys + part * quarter);
@@ -445,14 +439,34 @@ __global__ __launch_bounds__(256) void k_rank_select(const float *__restrict__ n
     cnt += __shfl_xor(cnt, 1);
     cnt += __shfl_xor(cnt, 2);
     if (part != 0 || i >= T1) return;
+    // this row's own maximum and its first argmax
+    float pv[MAX_WJ];
+    int pj[MAX_WJ];
+#pragma unroll
+    for (int p = 0; p < MAX_WJ; ++p) {
+        pv[p] = (p < nparts) ? pm[(int64_t)p * T1 + i] : -INFINITY;
+        pj[p] = (p < nparts) ? pi[(int64_t)p * T1 + i] : 0;
+    }
+    float best = pv[0];
+    int bidx = pj[0];
+#pragma unroll
+    for (int p = 1; p < MAX_WJ; ++p) {
+        const bool up = pv[p] > best;
+        best = up ? pv[p] : best;
+        bidx = up ? pj[p] : bidx;
+    }
+    if (class_token && i == 0) {
+        best = -INFINITY;
+        bidx = 0;
+    }
     const int U = T1 - r;
     const int64_t gi = (int64_t)g * T1 + i;
+    if (node_max) node_max[gi] = best;
     if (rank_out) rank_out[gi] = cnt;
     if (cnt < r) {
-        const int d = node_idx[gi];
         src_idx[(int64_t)g * r + cnt] = i;
-        dst_idx[(int64_t)g * r + cnt] = d;
-        if (row_map) row_map[gi] = out_row_dst(d, U, distill_token);
+        dst_idx[(int64_t)g * r + cnt] = bidx;
+        if (row_map) row_map[gi] = out_row_dst(bidx, U, distill_token);
     } else if (!class_token) {
         unm_idx[(int64_t)g * U + (cnt - r)] = i;
         if (row_map) row_map[gi] = out_row_unm(cnt - r, distill_token);
@@ -513,58 +527,13 @@ template <int OP> __device__ __forceinline__ float reduce_step(float acc, float 
     return acc;
 }
 
+// One destination row (odd token 2j+1 plus every source merged into it), whole wave, contract order:
+// own term first, then the sources in src_idx (rank) order found by ballot-scanning dst_idx.
 template <typename TX, typename TS, int VEC, int OP>
-__global__ __launch_bounds__(256) void k_merge_rows(const TX *__restrict__ x, const TS *__restrict__ size,
-                                                    int n, int T_, int C, int r,
-                                                    const int64_t *__restrict__ src_idx,
-                                                    const int64_t *__restrict__ dst_idx,
-                                                    const int64_t *__restrict__ unm_idx, int distill,
-                                                    const uint8_t *__restrict__ keep, TX *__restrict__ xout,
-                                                    TS *__restrict__ sout) {
-    const int lane = threadIdx.x & 63;
-    const int To = T_ - r;
-    const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (row >= (int64_t)n * To) return;
-    const int g = (int)(row / To);
-    const int o = (int)(row - (int64_t)g * To);
-    const int T1 = (T_ + 1) >> 1, U = T1 - r;
-
-    // inverse of the output layout (merge.py:82-85)
-    bool is_dst;
-    int idx;
-    if (!distill) {
-        is_dst = o >= U;
-        idx = is_dst ? o - U : o;
-    } else if (o == 0) { is_dst = false; idx = 0; }
-    else if (o == 1) { is_dst = true; idx = 0; }
-    else if (o <= U) { is_dst = false; idx = o - 1; }
-    else { is_dst = true; idx = o - U; }
-
-    const TX *xg = x + (int64_t)g * T_ * C;
-    const TS *sg = size ? size + (int64_t)g * T_ : nullptr;
-    TX *orow = xout + row * C;
-    const int64_t *srcg = src_idx ? src_idx + (int64_t)g * r : nullptr;
-    const int64_t *dstg = dst_idx ? dst_idx + (int64_t)g * r : nullptr;
-
-    if (!is_dst) {
-        const int t = 2 * (int)unm_idx[(int64_t)g * U + idx];
-        const TX *xr = xg + (int64_t)t * C;
-        float s = 1.0f;
-        if (OP == OP_WAVG) s = sg ? to_f32(sg[t]) : 1.0f;
-        for (int c = lane * VEC; c < C; c += WAVE * VEC) {
-            float v[VEC];
-            load_pack<TX, VEC>(xr + c, v);
-            if (OP == OP_WAVG) {
-#pragma unroll
-                for (int e = 0; e < VEC; ++e) v[e] = __fdiv_rn(__fmul_rn(v[e], s), s);
-            }
-            store_pack<TX, VEC>(orow + c, v);
-        }
-        if (OP == OP_WAVG && lane == 0) sout[row] = from_f32<TS>(s);
-        return;
-    }
-
-    const int j = idx;
+__device__ __forceinline__ void merge_dst_row(const TX *__restrict__ xg, const TS *__restrict__ sg, int C, int r,
+                                              int g, int j, const int64_t *__restrict__ srcg,
+                                              const int64_t *__restrict__ dstg, const uint8_t *__restrict__ keep,
+                                              TX *__restrict__ orow, TS *__restrict__ srow, int lane) {
     const int t = 2 * j + 1;
     const TX *xr = xg + (int64_t)t * C;
     float s_own = 1.0f;
@@ -649,7 +618,198 @@ __global__ __launch_bounds__(256) void k_merge_rows(const TX *__restrict__ x, co
             store_pack<TX, VEC>(orow + c, acc);
         }
     }
-    if (OP == OP_WAVG && lane == 0) sout[row] = from_f32<TS>(ssum);
+    if (OP == OP_WAVG && lane == 0) *srow = from_f32<TS>(ssum);
+}
+
+// inverse of the output layout (merge.py:82-85): output row o -> (is it a B/dst row?, index in its set)
+__device__ __forceinline__ void decode_out_row(int o, int U, int distill, bool &is_dst, int &idx) {
+    if (!distill) {
+        is_dst = o >= U;
+        idx = is_dst ? o - U : o;
+    } else if (o == 0) { is_dst = false; idx = 0; }
+    else if (o == 1) { is_dst = true; idx = 0; }
+    else if (o <= U) { is_dst = false; idx = o - 1; }
+    else { is_dst = true; idx = o - U; }
+}
+
+// Generic form: one wave per output row, any C / alignment / r.  (The hot shapes go through
+// k_merge_rows_fast below; this one serves odd channel counts such as the size column or source matrices.)
+template <typename TX, typename TS, int VEC, int OP>
+__global__ __launch_bounds__(256) void k_merge_rows(const TX *__restrict__ x, const TS *__restrict__ size,
+                                                    int n, int T_, int C, int r,
+                                                    const int64_t *__restrict__ src_idx,
+                                                    const int64_t *__restrict__ dst_idx,
+                                                    const int64_t *__restrict__ unm_idx, int distill,
+                                                    const uint8_t *__restrict__ keep, TX *__restrict__ xout,
+                                                    TS *__restrict__ sout) {
+    const int lane = threadIdx.x & 63;
+    const int To = T_ - r;
+    const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= (int64_t)n * To) return;
+    const int g = (int)(row / To);
+    const int o = (int)(row - (int64_t)g * To);
+    const int T1 = (T_ + 1) >> 1, U = T1 - r;
+    bool is_dst;
+    int idx;
+    decode_out_row(o, U, distill, is_dst, idx);
+
+    const TX *xg = x + (int64_t)g * T_ * C;
+    const TS *sg = size ? size + (int64_t)g * T_ : nullptr;
+    TX *orow = xout + row * C;
+    if (!is_dst) {
+        const int t = 2 * (int)unm_idx[(int64_t)g * U + idx];
+        const TX *xr = xg + (int64_t)t * C;
+        float s = 1.0f;
+        if (OP == OP_WAVG) s = sg ? to_f32(sg[t]) : 1.0f;
+        for (int c = lane * VEC; c < C; c += WAVE * VEC) {
+            float v[VEC];
+            load_pack<TX, VEC>(xr + c, v);
+            if (OP == OP_WAVG) {
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) v[e] = __fdiv_rn(__fmul_rn(v[e], s), s);
+            }
+            store_pack<TX, VEC>(orow + c, v);
+        }
+        if (OP == OP_WAVG && lane == 0) sout[row] = from_f32<TS>(s);
+        return;
+    }
+    merge_dst_row<TX, TS, VEC, OP>(xg, sg, C, r, g, idx, src_idx ? src_idx + (int64_t)g * r : nullptr,
+                                   dst_idx ? dst_idx + (int64_t)g * r : nullptr, keep, orow,
+                                   sout ? sout + row : nullptr, lane);
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_merge_rows_fast: the HBM-bound form for rows made of whole 16-byte chunks (C*sizeof(TX) % 16 == 0,
+// at most 384 chunks per R rows).  A wave owns R consecutive OUTPUT rows of one group, flattens their
+// R*cpr 16-byte chunks over its lanes (6 chunks per lane, every lane busy, stores contiguous across the
+// R rows) and issues all of its loads before touching any of them, so ~6 KiB per wave are in flight.
+// Rows that nothing merges into are moved as raw bits when their size is 1 ((x*1)/1 == x bit for bit)
+// or scaled in fp32 otherwise; the few rows that receive sources are finished by merge_dst_row.
+// ------------------------------------------------------------------------------------------------
+#define FAST_NIT 6
+#define FAST_MAXR 4
+
+template <typename TX, typename TS, int OP>
+__global__ __launch_bounds__(256) void k_merge_rows_fast(const TX *__restrict__ x, const TS *__restrict__ size,
+                                                         int n, int T_, int C, int r, int R, int cpr,
+                                                         const int64_t *__restrict__ src_idx,
+                                                         const int64_t *__restrict__ dst_idx,
+                                                         const int64_t *__restrict__ unm_idx, int distill,
+                                                         const uint8_t *__restrict__ keep, TX *__restrict__ xout,
+                                                         TS *__restrict__ sout) {
+    constexpr int VEC = 16 / sizeof(TX);
+    const int lane = threadIdx.x & 63;
+    const int To = T_ - r;
+    const int rg_per_group = (To + R - 1) / R;
+    const int64_t w = (int64_t)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (w >= (int64_t)n * rg_per_group) return;
+    const int g = (int)(w / rg_per_group);
+    const int o0 = (int)(w - (int64_t)g * rg_per_group) * R;
+    const int T1 = (T_ + 1) >> 1, U = T1 - r;
+    const TX *xg = x + (int64_t)g * T_ * C;
+    const TS *sg = size ? size + (int64_t)g * T_ : nullptr;
+    const int64_t *srcg = src_idx ? src_idx + (int64_t)g * r : nullptr;
+    const int64_t *dstg = dst_idx ? dst_idx + (int64_t)g * r : nullptr;
+
+    // per-row facts, computed by lanes 0..R-1 in parallel (one index load, then one size load) and
+    // broadcast as wave-uniform scalars: source token, size, B-row number, "something merges into it"
+    int my_tok = 0, my_j = -1;
+    float my_s = 1.0f;
+    bool my_valid = false;
+    if (lane < R) {
+        const int o = o0 + lane;
+        if (o < To) {
+            my_valid = true;
+            bool is_dst;
+            int idx;
+            decode_out_row(o, U, distill, is_dst, idx);
+            if (is_dst) {
+                my_tok = 2 * idx + 1;
+                my_j = idx;
+            } else {
+                my_tok = 2 * (int)unm_idx[(int64_t)g * U + idx];
+            }
+            if (OP == OP_WAVG && sg) my_s = to_f32(sg[my_tok]);
+        }
+    }
+    const unsigned long long vmask = __ballot(my_valid);
+    const int tok0 = __builtin_amdgcn_readlane(my_tok, 0), tok1 = __builtin_amdgcn_readlane(my_tok, 1),
+              tok2 = __builtin_amdgcn_readlane(my_tok, 2), tok3 = __builtin_amdgcn_readlane(my_tok, 3);
+    const int j0 = __builtin_amdgcn_readlane(my_j, 0), j1 = __builtin_amdgcn_readlane(my_j, 1),
+              j2 = __builtin_amdgcn_readlane(my_j, 2), j3 = __builtin_amdgcn_readlane(my_j, 3);
+    const float sz0 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(my_s), 0)),
+                sz1 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(my_s), 1)),
+                sz2 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(my_s), 2)),
+                sz3 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(my_s), 3));
+    bool e0 = false, e1 = false, e2 = false, e3 = false;  // rows that receive sources
+    if (OP != OP_DROP) {
+        for (int base = 0; base < r; base += WAVE) {
+            const int k = base + lane;
+            const int d = (k < r) ? (int)dstg[k] : -2;
+            e0 = e0 || (__ballot(d == j0) != 0ull);
+            e1 = e1 || (__ballot(d == j1) != 0ull);
+            e2 = e2 || (__ballot(d == j2) != 0ull);
+            e3 = e3 || (__ballot(d == j3) != 0ull);
+        }
+    }
+    const bool ok0 = (vmask & 1ull) && !e0, ok1 = (vmask & 2ull) && !e1, ok2 = (vmask & 4ull) && !e2,
+               ok3 = (vmask & 8ull) && !e3;
+
+    // flattened chunk loop: chunk q of the R-row slab -> (row q / cpr, 16-byte column q % cpr)
+    const int total = R * cpr;
+    uint4 raw[FAST_NIT];
+    int rowof[FAST_NIT];
+#pragma unroll
+    for (int it = 0; it < FAST_NIT; ++it) {
+        const int q = it * WAVE + lane;
+        const int rr = (q >= cpr) + (q >= 2 * cpr) + (q >= 3 * cpr);
+        const int cc = q - rr * cpr;
+        const int t = rr == 0 ? tok0 : (rr == 1 ? tok1 : (rr == 2 ? tok2 : tok3));
+        const bool ok = (rr == 0 ? ok0 : (rr == 1 ? ok1 : (rr == 2 ? ok2 : ok3))) && (q < total);
+        rowof[it] = ok ? rr : -1;
+        if (ok) raw[it] = *reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(xg + (int64_t)t * C) + cc * 16);
+    }
+    char *obase = reinterpret_cast<char *>(xout + ((int64_t)g * To + o0) * C);
+    // (x*s)/s is x itself when s is 1, and also when s is a power of two and x came from a 16-bit
+    // format (the fp32 product cannot overflow): those rows move as raw bits
+    constexpr bool narrow = sizeof(TX) == 2;
+#pragma unroll
+    for (int it = 0; it < FAST_NIT; ++it) {
+        const int rr = rowof[it];
+        if (rr < 0) continue;
+        const int q = it * WAVE + lane;
+        const float s = rr == 0 ? sz0 : (rr == 1 ? sz1 : (rr == 2 ? sz2 : sz3));
+        uint4 outv = raw[it];
+        if (OP == OP_WAVG) {
+            const uint32_t sb = __float_as_uint(s);
+            const bool exact = (s == 1.0f) || (narrow && (sb & 0x007FFFFFu) == 0u && s >= 1.0f && s <= 65536.0f);
+            if (!exact) {
+                Pack<TX, VEC> pk;
+                __builtin_memcpy(&pk, &raw[it], 16);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) pk.e[e] = from_f32<TX>(__fdiv_rn(__fmul_rn(to_f32(pk.e[e]), s), s));
+                __builtin_memcpy(&outv, &pk, 16);
+            }
+        }
+        *reinterpret_cast<uint4 *>(obase + (int64_t)q * 16) = outv;
+    }
+    if (OP == OP_WAVG && lane < R && my_valid) {
+        const bool mine_has_edges = lane == 0 ? e0 : (lane == 1 ? e1 : (lane == 2 ? e2 : e3));
+        if (!mine_has_edges) sout[(int64_t)g * To + o0 + lane] = from_f32<TS>(my_s);
+    }
+    // rows that receive sources: sequential weighted sum in the contract's order
+    if ((vmask & 1ull) && e0)
+        merge_dst_row<TX, TS, VEC, OP>(xg, sg, C, r, g, j0, srcg, dstg, keep, xout + ((int64_t)g * To + o0) * C,
+                                       sout ? sout + (int64_t)g * To + o0 : nullptr, lane);
+    if ((vmask & 2ull) && e1)
+        merge_dst_row<TX, TS, VEC, OP>(xg, sg, C, r, g, j1, srcg, dstg, keep, xout + ((int64_t)g * To + o0 + 1) * C,
+                                       sout ? sout + (int64_t)g * To + o0 + 1 : nullptr, lane);
+    if ((vmask & 4ull) && e2)
+        merge_dst_row<TX, TS, VEC, OP>(xg, sg, C, r, g, j2, srcg, dstg, keep, xout + ((int64_t)g * To + o0 + 2) * C,
+                                       sout ? sout + (int64_t)g * To + o0 + 2 : nullptr, lane);
+    if ((vmask & 8ull) && e3)
+        merge_dst_row<TX, TS, VEC, OP>(xg, sg, C, r, g, j3, srcg, dstg, keep, xout + ((int64_t)g * To + o0 + 3) * C,
+                                       sout ? sout + (int64_t)g * To + o0 + 3 : nullptr, lane);
 }
 
 // k_unmerge_rows: merge.py:87-100 as a scatter from the merged sequence: one wave per INPUT row; a
@@ -772,8 +932,8 @@ extern "C" int tome_profile_read(float *stage_ms, int max_stages) {
 }
 
 struct MatchWs {
-    float *unitA, *unitB, *node_max;
-    int *node_idx, *rank;
+    float *unitA, *unitB, *part_max;
+    int *part_idx, *rank;
     int ntA, ntB, nchunk;
     int64_t groupA_f4, groupB_f4;  // float4 per group of each unit set
     size_t bytes;
@@ -791,8 +951,8 @@ static MatchWs carve(void *base, int64_t n, int64_t T, int64_t D) {
     char *b = (char *)base;
     w.unitA = (float *)(b + off); off = align_up(off + 16 * (size_t)(n * w.groupA_f4), 256);
     w.unitB = (float *)(b + off); off = align_up(off + 16 * (size_t)(n * w.groupB_f4), 256);
-    w.node_max = (float *)(b + off); off = align_up(off + sizeof(float) * (size_t)(n * T1), 256);
-    w.node_idx = (int *)(b + off); off = align_up(off + sizeof(int) * (size_t)(n * T1), 256);
+    w.part_max = (float *)(b + off); off = align_up(off + sizeof(float) * (size_t)(n * MAX_WJ * T1), 256);
+    w.part_idx = (int *)(b + off); off = align_up(off + sizeof(int) * (size_t)(n * MAX_WJ * T1), 256);
     w.rank = (int *)(b + off); off = align_up(off + sizeof(int) * (size_t)(n * T1), 256);
     w.bytes = off;
     return w;
@@ -803,25 +963,20 @@ extern "C" size_t tome_match_workspace_bytes(int64_t n, int64_t T, int64_t D) {
     return carve(nullptr, n, T, D).bytes;
 }
 
-static int launch_select(const MatchWs &w, int64_t n, int64_t T, int64_t re, int class_token,
+static int launch_select(const MatchWs &w, int nparts, int64_t n, int64_t T, int64_t re, int class_token,
                          int distill_token, int64_t *src_idx, int64_t *dst_idx, int64_t *unm_idx,
                          float *node_max, int32_t *row_map, hipStream_t st) {
     const int T1 = (int)((T + 1) / 2);
     dim3 grid((T1 + 63) / 64, (unsigned)n);
     const int quarter = (((T1 + 3) >> 2) + 1) & ~1;
     const size_t lds = sizeof(unsigned long long) * (size_t)(4 * quarter);
-    hipLaunchKernelGGL(k_rank_select, grid, dim3(256), lds, st, w.node_max, w.node_idx, (int)n, T1, (int)re,
-                       class_token, distill_token, src_idx, dst_idx, unm_idx, w.rank, row_map);
+    hipLaunchKernelGGL(k_rank_select, grid, dim3(256), lds, st, w.part_max, w.part_idx, nparts, (int)n, T1, (int)re,
+                       class_token, distill_token, src_idx, dst_idx, unm_idx, node_max, w.rank, row_map);
     if (int rc = check_launch("k_rank_select")) return rc;
     if (class_token) {
         hipLaunchKernelGGL(k_compact_unm, dim3((unsigned)n), dim3(256), 0, st, w.rank, T1, (int)re,
                            distill_token, unm_idx, row_map);
         if (int rc = check_launch("k_compact_unm")) return rc;
-    }
-    if (node_max) {
-        hipError_t e = hipMemcpyAsync(node_max, w.node_max, sizeof(float) * (size_t)(n * T1),
-                                      hipMemcpyDeviceToDevice, st);
-        if (e != hipSuccess) return fail(TOME_ELAUNCH, "node_max copy: %s", hipGetErrorString(e));
     }
     return TOME_OK;
 }
@@ -893,26 +1048,31 @@ extern "C" int tome_match(const void *metric, int dtype, int64_t n, int64_t T, i
     if (int rc = check_launch("k_unit_rows")) return rc;
     prof_mark(1, st);
 
-    // 2. similarity + row max/argmax: one workgroup per (group, A tile), WJ waves split the B tiles so
-    // that the launch has about three waves per SIMD (1024 SIMDs) whatever the batch
-    int WJ = (int)((3072 + n * w.ntA - 1) / (n * w.ntA));
+    // 2. similarity + row max/argmax: one single-wave workgroup per (group, A tile, j-part); the B tiles are
+    // split into WJ parts so that the launch has >= ~6 waves per SIMD (1024 SIMDs) whatever the batch
+    static const long target_waves = [] {
+        const char *e = getenv("TOME_SCORES_WAVES");  // tuning knob, default from measurements on MI355X
+        long v = e ? atol(e) : 0;
+        return v > 0 ? v : 6144L;
+    }();
+    int WJ = (int)((target_waves + n * w.ntA - 1) / (n * w.ntA));
     if (WJ > MAX_WJ) WJ = MAX_WJ;
     if (WJ > w.ntB) WJ = w.ntB;
     if (WJ < 1) WJ = 1;
-    const unsigned nb2 = (unsigned)(((n + 7) / 8) * 8 * w.ntA);
+    const unsigned nb2 = (unsigned)(((n + 7) / 8) * 8 * w.ntA * WJ);
     if (w.nchunk == 1)
-        hipLaunchKernelGGL(k_scores_rowmax<true>, dim3(nb2), dim3(64 * WJ), 0, st, (const f32x4 *)w.unitA,
-                           (const f32x4 *)w.unitB, (int)n, T1, T2, w.nchunk, w.ntA, w.ntB, w.groupA_f4, w.groupB_f4,
-                           class_token, distill_token, w.node_max, w.node_idx);
+        hipLaunchKernelGGL(k_scores_rowmax<true>, dim3(nb2), dim3(64), 0, st, (const f32x4 *)w.unitA,
+                           (const f32x4 *)w.unitB, (int)n, T1, T2, w.nchunk, w.ntA, w.ntB, WJ, w.groupA_f4,
+                           w.groupB_f4, distill_token, w.part_max, w.part_idx);
     else
-        hipLaunchKernelGGL(k_scores_rowmax<false>, dim3(nb2), dim3(64 * WJ), 0, st, (const f32x4 *)w.unitA,
-                           (const f32x4 *)w.unitB, (int)n, T1, T2, w.nchunk, w.ntA, w.ntB, w.groupA_f4, w.groupB_f4,
-                           class_token, distill_token, w.node_max, w.node_idx);
+        hipLaunchKernelGGL(k_scores_rowmax<false>, dim3(nb2), dim3(64), 0, st, (const f32x4 *)w.unitA,
+                           (const f32x4 *)w.unitB, (int)n, T1, T2, w.nchunk, w.ntA, w.ntB, WJ, w.groupA_f4,
+                           w.groupB_f4, distill_token, w.part_max, w.part_idx);
     if (int rc = check_launch("k_scores_rowmax")) return rc;
     prof_mark(2, st);
 
     // 3. rank + select
-    int rc = launch_select(w, n, T, re, class_token, distill_token, src_idx, dst_idx, unm_idx, node_max, row_map, st);
+    int rc = launch_select(w, WJ, n, T, re, class_token, distill_token, src_idx, dst_idx, unm_idx, node_max, row_map, st);
     prof_mark(3, st);
     g_prof.valid = g_prof.on && rc == TOME_OK;
     return rc;
@@ -935,9 +1095,10 @@ extern "C" int tome_match_scores(const float *scores, int64_t n, int64_t T, int6
     const int T1 = (int)((T + 1) / 2), T2 = (int)(T / 2);
     const unsigned nb = (unsigned)((n * T1 + 3) / 4);
     hipLaunchKernelGGL(k_rowmax_given, dim3(nb), dim3(256), 0, st, scores, (int)n, T1, T2, class_token,
-                       distill_token, w.node_max, w.node_idx);
+                       distill_token, w.part_max, w.part_idx);
     if (int rc = check_launch("k_rowmax_given")) return rc;
-    return launch_select(w, n, T, re, class_token, distill_token, src_idx, dst_idx, unm_idx, node_max, row_map, st);
+    return launch_select(w, 1, n, T, re, class_token, distill_token, src_idx, dst_idx, unm_idx, node_max, row_map,
+                         st);
 }
 
 extern "C" int tome_edge_keep(const float *node_max, const int64_t *src_idx, int64_t n, int64_t T, int64_t r,
@@ -957,9 +1118,20 @@ static int launch_merge_rows(const void *x, const void *size, int64_t n, int64_t
                              const int64_t *src, const int64_t *dst, const int64_t *unm, int distill,
                              const uint8_t *keep, void *xout, void *sout, hipStream_t st) {
     constexpr int VEC = 16 / sizeof(TX);
-    const int64_t rows = n * (T - r);
-    const unsigned nb = (unsigned)((rows + 3) / 4);
+    const int64_t To = T - r;
     const bool vec_ok = (C % VEC == 0) && aligned16(x) && aligned16(xout);
+    const int64_t cpr = C / VEC;  // 16-byte chunks per row
+    if (vec_ok && cpr <= FAST_NIT * WAVE) {
+        int R = (int)((FAST_NIT * WAVE) / cpr);
+        if (R > FAST_MAXR) R = FAST_MAXR;
+        const int64_t waves = n * ((To + R - 1) / R);
+        hipLaunchKernelGGL((k_merge_rows_fast<TX, TS, OP>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st,
+                           (const TX *)x, (const TS *)size, (int)n, (int)T, (int)C, (int)r, R, (int)cpr, src, dst, unm,
+                           distill, keep, (TX *)xout, (TS *)sout);
+        return check_launch("k_merge_rows_fast");
+    }
+    const int64_t rows = n * To;
+    const unsigned nb = (unsigned)((rows + 3) / 4);
     if (vec_ok)
         hipLaunchKernelGGL((k_merge_rows<TX, TS, VEC, OP>), dim3(nb), dim3(256), 0, st, (const TX *)x,
                            (const TS *)size, (int)n, (int)T, (int)C, (int)r, src, dst, unm, distill, keep, (TX *)xout,
