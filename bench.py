@@ -49,7 +49,7 @@ def parse():
     ap.add_argument("--frames", type=int, default=16)
     ap.add_argument("--r", type=int, default=16)
     ap.add_argument("--cpu-clips", type=int, default=2, help="batch of the CPU baseline sample")
-    ap.add_argument("--cpu-iters", type=int, default=4)
+    ap.add_argument("--cpu-iters", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     return ap.parse_args()
@@ -86,18 +86,18 @@ def measure_kernels(batch: int, t0: int, r: int, dev, reps: int = 10):
         assert x.shape[1] == t
         metric = torch.randn(batch, t, HEAD_DIM, device=dev, generator=g).bfloat16()
         # --- matching: per-stage events recorded inside tome_match
-        _abi.profile_enable(True)
+        _abi.profile_enable(reps)  # every stage kernel is launched `reps` times back to back between events
         acc = [0.0, 0.0, 0.0]
         plan = None
-        for i in range(reps + 2):
+        for i in range(3):
             plan = _abi.match(metric, re)
             ms = _abi.profile_read()
-            if i >= 2:
-                acc = [a + b for a, b in zip(acc, ms)]
-        _abi.profile_enable(False)
+            if i >= 1:
+                acc = [a + b / 2 for a, b in zip(acc, ms)]
+        _abi.profile_enable(0)
         t1, t2 = (t + 1) // 2, t // 2
         for name, ms in zip(("k_unit_rows", "k_scores_rowmax", "k_rank_select"), acc):
-            stats[name]["ms"] += ms / reps
+            stats[name]["ms"] += ms
             stats[name]["launches"] += 1
         stats["k_unit_rows"]["bytes"] += batch * t * HEAD_DIM * (2 + 4)      # read bf16 keys, write fp32 units
         stats["k_scores_rowmax"]["flops"] += batch * 2 * t1 * t2 * HEAD_DIM
@@ -152,12 +152,28 @@ def roofline_of(stats):
             "avg_launch_us": round(s["ms"] * 1e3 / s["launches"], 2)}
 
 
+def usable_cpus() -> int:
+    """Host cores this process may actually use: the scheduler affinity mask, capped by the cgroup CPU
+    quota when there is one (a GPU box hands each job a share of the host, not all of it)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    cap = int(os.environ.get("TOME_BENCH_CPU_THREADS", "0"))
+    if cap > 0:
+        n = min(n, cap)
+    return max(1, min(n, 64))
+
+
 def cpu_baseline(frames: int, r: int, clips: int, iters: int):
     """The reference's PyTorch-CPU path (fp32) on a bounded sample: `iters` forwards of `clips` clips."""
     from hosts.videomae import videomae_base
     from oracle import torch_port
     torch.manual_seed(0)
-    threads = os.cpu_count() or 1
+    threads = usable_cpus()
     torch.set_num_threads(threads)
     host = videomae_base(num_frames=frames).eval()
     x = torch.rand(clips, 3, frames, 224, 224)
@@ -204,13 +220,10 @@ def main():
     labels = torch.randint(0, 400, (B,), device=dev, generator=gen)
     counts = torch.zeros(3, dtype=torch.int64, device=dev)  # top1, top5, clips
 
+    from hosts.evalloop import all_reduce_counts, topk_counts
+
     def step():
-        logits = model([clips])
-        top5 = logits.float().topk(5, dim=1).indices
-        hit = top5 == labels[:, None]
-        counts[0] += hit[:, 0].sum()
-        counts[1] += hit.any(dim=1).sum()
-        counts[2] += B
+        counts.add_(topk_counts(model([clips]), labels))
 
     with torch.no_grad():
         for _ in range(args.warmup):
@@ -222,8 +235,7 @@ def main():
         t_start = time.perf_counter()
         for _ in range(args.steps):
             step()
-        if world > 1:
-            dist.all_reduce(counts)  # the one collective: top-1 / top-5 / clip counts over xGMI
+        all_reduce_counts(counts)  # the one collective: top-1 / top-5 / clip counts over xGMI (no-op at N=1)
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()

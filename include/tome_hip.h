@@ -117,10 +117,12 @@ int tome_unmerge(const void *x, int dtype, int64_t n, int64_t T, int64_t C, int6
                  tome_stream_t stream);
 
 /*
- * Measurement aid (bench.py): when enabled on the calling thread, tome_match records HIP events between
- * its kernels on the caller's stream; tome_profile_read waits for the last profiled call and returns the
- * milliseconds of its stages {unit vectors, similarity+row max, rank+select}.  Events are created by
- * tome_profile_enable(1), never inside a launch path.  No reference counterpart.
+ * Measurement aid (bench.py): tome_profile_enable(reps > 0) makes tome_match on the calling thread record
+ * HIP events between its stages on the caller's stream and launch every stage kernel `reps` times back to
+ * back (the kernels are pure functions of their inputs, results are unchanged); tome_profile_read waits for
+ * the last profiled call and returns the milliseconds PER LAUNCH of the stages {unit vectors,
+ * similarity+row max, rank+select}.  Events are created by tome_profile_enable, never inside a launch
+ * path; tome_profile_enable(0) switches it off.  No reference counterpart.
  */
 int tome_profile_enable(int on);
 int tome_profile_read(float *stage_ms, int max_stages);

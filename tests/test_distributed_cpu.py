@@ -1,0 +1,69 @@
+"""N>1 path on CPU: two gloo ranks shard a clip set, count top-1/top-5 locally and meet in ONE
+all-reduce; the result must equal the single-process count."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "video-how-do-your-tokens-merge_amd"))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, total, out_dir):
+    sys.path.insert(0, os.path.join(ROOT, "video-how-do-your-tokens-merge_amd"))
+    from hosts.evalloop import all_reduce_counts, shard_range, topk_counts
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = torch.Generator().manual_seed(123)
+    logits = torch.randn(total, 50, generator=g)
+    labels = torch.randint(0, 50, (total,), generator=g)
+    lo, hi = shard_range(total, rank, world)
+    counts = torch.zeros(3, dtype=torch.int64)
+    for a in range(lo, hi, 4):  # a few local steps, accumulate on "device"
+        b = min(hi, a + 4)
+        counts += topk_counts(logits[a:b], labels[a:b])
+    all_reduce_counts(counts)
+    torch.save(counts, os.path.join(out_dir, f"r{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("total", [37, 64])
+def test_two_ranks_one_allreduce(tmp_path, total):
+    from hosts.evalloop import shard_range, topk_counts
+    world = 2
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, total, str(tmp_path)), nprocs=world, join=True)
+    g = torch.Generator().manual_seed(123)
+    logits = torch.randn(total, 50, generator=g)
+    labels = torch.randint(0, 50, (total,), generator=g)
+    want = topk_counts(logits, labels)
+    for r in range(world):
+        got = torch.load(os.path.join(str(tmp_path), f"r{r}.pt"), weights_only=True)
+        assert torch.equal(got, want), (got, want)
+    assert want[2].item() == total and want[1] >= want[0]
+    # shards tile the range
+    spans = [shard_range(total, r, world) for r in range(world)]
+    assert spans[0][0] == 0 and spans[-1][1] == total and spans[0][1] == spans[1][0]
+
+
+def test_shard_range_properties():
+    from hosts.evalloop import shard_range
+    for total in (0, 1, 7, 8, 100):
+        for world in (1, 2, 3, 8):
+            spans = [shard_range(total, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == total
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1

@@ -900,6 +900,7 @@ static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; 
 static thread_local struct {
     bool on = false;
     bool valid = false;
+    int reps = 1;  // each stage kernel is launched this many times between its two events (idempotent kernels)
     hipEvent_t ev[PROF_EVENTS];
 } g_prof;
 
@@ -913,10 +914,13 @@ extern "C" int tome_profile_enable(int on) {
             if (hipEventCreate(&g_prof.ev[i]) != hipSuccess) return fail(TOME_ELAUNCH, "hipEventCreate failed");
         g_prof.on = true;
         g_prof.valid = false;
-    } else if (!on && g_prof.on) {
+    }
+    if (on) g_prof.reps = on;
+    if (!on && g_prof.on) {
         for (int i = 0; i < PROF_EVENTS; ++i) (void)hipEventDestroy(g_prof.ev[i]);
         g_prof.on = false;
         g_prof.valid = false;
+        g_prof.reps = 1;
     }
     return TOME_OK;
 }
@@ -925,9 +929,11 @@ extern "C" int tome_profile_read(float *stage_ms, int max_stages) {
     if (!g_prof.on || !g_prof.valid || !stage_ms) return fail(TOME_EINVAL, "tome_profile_read: no profiled call");
     if (hipEventSynchronize(g_prof.ev[PROF_EVENTS - 1]) != hipSuccess)
         return fail(TOME_ELAUNCH, "tome_profile_read: event synchronize failed");
-    for (int i = 0; i + 1 < PROF_EVENTS && i < max_stages; ++i)
+    for (int i = 0; i + 1 < PROF_EVENTS && i < max_stages; ++i) {
         if (hipEventElapsedTime(&stage_ms[i], g_prof.ev[i], g_prof.ev[i + 1]) != hipSuccess)
             return fail(TOME_ELAUNCH, "tome_profile_read: elapsed time failed");
+        stage_ms[i] /= (float)g_prof.reps;
+    }
     return TOME_OK;
 }
 
@@ -1006,6 +1012,9 @@ extern "C" int tome_match(const void *metric, int dtype, int64_t n, int64_t T, i
     const bool fast = (D % 8 == 0) && (((uintptr_t)metric) % 16 == 0) && ((stride_n * es) % 16 == 0) &&
                       ((stride_t * es) % 16 == 0);
     bool launched = false;
+    const int prof_reps = g_prof.on ? g_prof.reps : 1;
+    for (int rep = 0; rep < prof_reps; ++rep) {
+    launched = false;
 #define UNIT_FAST(TY, NCH)                                                                                    \
     hipLaunchKernelGGL((k_unit_rows<TY, NCH>), dim3((unsigned)((n * T + 31) / 32)), dim3(256), 0, st,          \
                        (const TY *)metric, stride_n, stride_t, (int)n, (int)T, (int)D, w.unitA, w.unitB,       \
@@ -1045,6 +1054,7 @@ extern "C" int tome_match(const void *metric, int dtype, int64_t n, int64_t T, i
 #undef UNIT_FAST
 #undef UNIT_NCH
 #undef UNIT_GENERIC
+    }
     if (int rc = check_launch("k_unit_rows")) return rc;
     prof_mark(1, st);
 
@@ -1060,6 +1070,7 @@ extern "C" int tome_match(const void *metric, int dtype, int64_t n, int64_t T, i
     if (WJ > w.ntB) WJ = w.ntB;
     if (WJ < 1) WJ = 1;
     const unsigned nb2 = (unsigned)(((n + 7) / 8) * 8 * w.ntA * WJ);
+    for (int rep = 0; rep < prof_reps; ++rep)
     if (w.nchunk == 1)
         hipLaunchKernelGGL(k_scores_rowmax<true>, dim3(nb2), dim3(64), 0, st, (const f32x4 *)w.unitA,
                            (const f32x4 *)w.unitB, (int)n, T1, T2, w.nchunk, w.ntA, w.ntB, WJ, w.groupA_f4,
@@ -1072,7 +1083,9 @@ extern "C" int tome_match(const void *metric, int dtype, int64_t n, int64_t T, i
     prof_mark(2, st);
 
     // 3. rank + select
-    int rc = launch_select(w, WJ, n, T, re, class_token, distill_token, src_idx, dst_idx, unm_idx, node_max, row_map, st);
+    int rc = TOME_OK;
+    for (int rep = 0; rep < prof_reps && rc == TOME_OK; ++rep)
+        rc = launch_select(w, WJ, n, T, re, class_token, distill_token, src_idx, dst_idx, unm_idx, node_max, row_map, st);
     prof_mark(3, st);
     g_prof.valid = g_prof.on && rc == TOME_OK;
     return rc;

@@ -281,8 +281,9 @@ def unmerge(plan: MatchPlan, x: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def profile_enable(on: bool) -> None:
-    _check(lib().tome_profile_enable(int(on)), "tome_profile_enable")
+def profile_enable(reps: int) -> None:
+    """reps > 0: time tome_match's stages, each kernel launched `reps` times back to back; 0: off."""
+    _check(lib().tome_profile_enable(int(reps)), "tome_profile_enable")
 
 
 def profile_read():
