@@ -1,0 +1,233 @@
+#!/usr/bin/env python3
+"""Golden vectors of the reference's PATCHED MODELS at reduced width.  Build container only (reads
+/root/reference); the GPU box never runs this.
+
+The reference's `tome.patch.{videomae,timesformer,motionformer}` and the slowfast model files they patch
+are imported from /root/reference with the missing third-party modules (timm, fvcore, torchvision, ...)
+replaced by minimal in-memory stand-ins that provide only names (no arithmetic): the arithmetic that
+produces the fixtures is the reference's own.  ViViT cannot be imported (installed transformers lacks
+VivitSelfAttention) and has no block-level fixture.
+
+Per model the fixture (models_<name>.npz) holds: the logits of the patched forward, the final token sizes and
+per layer the matching's indices; the manifest holds the clip seed, the weight seed (weights are filled by
+tests/synth.fill_parameters, keyed by parameter NAME, so no state_dict is shipped) and the parameter names.  Seeds are searched until every layer is certified with
+tau = 1e-4 (the GPU run's upstream GEMMs differ from CPU in the last bits, so margins must be wide).
+"""
+from __future__ import annotations
+
+import importlib
+import importlib.util
+import json
+import math
+import os
+import sys
+import types
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+import synth  # noqa: E402
+
+REF = os.environ.get("TOME_REFERENCE", "/root/reference")
+TAU = 1e-4
+
+
+def install_stubs():
+    def pkg(name, path=None):
+        m = types.ModuleType(name)
+        m.__path__ = [path] if path else []
+        sys.modules[name] = m
+        return m
+
+    pkg("slowfast", os.path.join(REF, "slowfast"))
+    pkg("slowfast.models", os.path.join(REF, "slowfast", "models"))
+    build = types.ModuleType("slowfast.models.build")
+
+    class _Reg:
+        def register(self):
+            return lambda cls: cls
+    build.MODEL_REGISTRY = _Reg()
+    sys.modules["slowfast.models.build"] = build
+    pkg("tome", os.path.join(REF, "tome"))
+    pkg("tome.patch", os.path.join(REF, "tome", "patch"))
+
+    timm = pkg("timm")
+    models = pkg("timm.models")
+    layers = types.ModuleType("timm.models.layers")
+
+    def drop_path(x, drop_prob=0.0, training=False):
+        assert not training or not drop_prob
+        return x
+
+    class DropPath(torch.nn.Module):
+        def __init__(self, drop_prob=None):
+            super().__init__()
+            self.drop_prob = drop_prob
+
+        def forward(self, x):
+            return drop_path(x, self.drop_prob, self.training)
+    layers.drop_path, layers.DropPath = drop_path, DropPath
+    layers.to_2tuple = lambda v: v if isinstance(v, tuple) else (v, v)
+    layers.trunc_normal_ = torch.nn.init.trunc_normal_
+    sys.modules["timm.models.layers"] = layers
+    reg = types.ModuleType("timm.models.registry")
+    reg.register_model = lambda f: f
+    sys.modules["timm.models.registry"] = reg
+    resnet = types.ModuleType("timm.models.resnet")
+    resnet.resnet26d = resnet.resnet50d = None
+    sys.modules["timm.models.resnet"] = resnet
+    data = types.ModuleType("timm.data")
+    data.IMAGENET_DEFAULT_MEAN, data.IMAGENET_DEFAULT_STD = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
+    sys.modules["timm.data"] = data
+    timm.models, models.layers, models.registry, models.resnet, timm.data = models, layers, reg, resnet, data
+    tv = pkg("torchvision")
+    tvu = types.ModuleType("torchvision.utils")
+    tvu.make_grid = tvu.save_image = None  # names only
+    sys.modules["torchvision.utils"] = tvu
+    tv.utils = tvu
+
+
+def certificate(metric: torch.Tensor, r: int, cls: bool):
+    m = metric.double()
+    m = m / m.norm(dim=-1, keepdim=True)
+    s = m[:, ::2] @ m[:, 1::2].transpose(-1, -2)
+    if cls:
+        s[:, 0, :] = -math.inf
+    nmax, _ = s.max(-1)
+    order = nmax.argsort(dim=-1, descending=True, stable=True)
+    snm = nmax.gather(-1, order)
+    gaps = torch.nan_to_num(snm[:, :-1] - snm[:, 1:], nan=math.inf)
+    g_src = gaps[:, :r].min().item() if r > 0 else math.inf
+    g_unm = gaps[:, r:].min().item() if gaps.shape[1] > r else math.inf
+    rows = order[:, :r]
+    if s.shape[2] > 1:
+        top2 = s.gather(1, rows[..., None].expand(-1, -1, s.shape[2])).topk(2, dim=-1).values
+        g_dst = torch.nan_to_num(top2[..., 0] - top2[..., 1], nan=math.inf).min().item()
+    else:
+        g_dst = math.inf
+    return min(g_src, g_dst, g_src if cls else g_unm)
+
+
+def closure_vars(fn):
+    return dict(zip(fn.__code__.co_freevars, (c.cell_contents for c in fn.__closure__)))
+
+
+def run_traced(patch_mod, model, clip, r, cls=False):
+    """Forward of the patched reference model, recording every matching (metric, indices)."""
+    layers = []
+    orig = patch_mod.bipartite_soft_matching
+
+    def spy(metric, r_, class_token=False, distill_token=False, mode="merge"):
+        merge, unmerge = orig(metric, r_, class_token, distill_token, mode)
+        if getattr(merge, "__closure__", None):
+            cv = closure_vars(merge)
+            layers.append(dict(T=metric.shape[1], n=metric.shape[0], r=int(cv["r"]), metric=metric.detach().clone(),
+                               src=cv["src_idx"][..., 0].numpy().astype(np.int16),
+                               dst=cv["dst_idx"][..., 0].numpy().astype(np.int16),
+                               unm=cv["unm_idx"][..., 0].numpy().astype(np.int16)))
+        return merge, unmerge
+    patch_mod.bipartite_soft_matching = spy
+    try:
+        model.r = r
+        with torch.no_grad():
+            out = model([clip])
+    finally:
+        patch_mod.bipartite_soft_matching = orig
+    return out, layers
+
+
+def emit(name, model, wrapper_info, clip_shape, r, patch_mod, cls, extra, out_dir, prop_attn):
+    best = None
+    for attempt in range(300):
+        seed = 4000 + 7 * attempt
+        clip = torch.from_numpy(synth.uniform01(clip_shape, seed))
+        out, layers = run_traced(patch_mod, model, clip, r, cls)
+        margin = min(certificate(l["metric"], l["r"], cls) for l in layers)
+        if best is None or margin > best[0]:
+            best = (margin, seed, out, layers)
+        if margin > TAU:
+            break
+    margin, seed, out, layers = best
+    arrays = {"logits": out.numpy(), "size": wrapper_info()["size"].numpy()}
+    # re-run so that wrapper_info()["size"] belongs to the chosen seed
+    clip = torch.from_numpy(synth.uniform01(clip_shape, seed))
+    out, layers = run_traced(patch_mod, model, clip, r, cls)
+    arrays = {"logits": out.numpy(), "size": wrapper_info()["size"].numpy()}
+    for i, l in enumerate(layers):
+        arrays[f"L{i}_src"], arrays[f"L{i}_dst"], arrays[f"L{i}_unm"] = l["src"], l["dst"], l["unm"]
+    np.savez_compressed(os.path.join(out_dir, f"models_{name}.npz"), **arrays)
+    meta = dict(name=name, clip_shape=list(clip_shape), seed=seed, r=r, margin=margin, certified=bool(margin > TAU),
+                tokens=[l["T"] for l in layers], r_eff=[l["r"] for l in layers], groups=[l["n"] for l in layers],
+                prop_attn=prop_attn, **extra)
+    print(meta, flush=True)
+    return meta
+
+
+def main():
+    install_stubs()
+    torch.manual_seed(0)
+    metas = []
+    # ---- VideoMAE (tome/patch/videomae.py over videomae_video_model_builder.py)
+    vm = importlib.import_module("slowfast.models.videomae_video_model_builder")
+    pv = importlib.import_module("tome.patch.videomae")
+    cfgv = dict(img_size=32, patch_size=8, embed_dim=32, depth=4, num_heads=2, mlp_ratio=4, qkv_bias=True,
+                num_classes=10, all_frames=8, tubelet_size=2, init_values=0.0, init_scale=1.0)
+    for prop in (False, True):
+        torch.manual_seed(11)
+        inner = vm.VisionTransformer(norm_layer=lambda d: torch.nn.LayerNorm(d, eps=1e-6), **cfgv).eval()
+        wrap = torch.nn.Module()
+        wrap.__class__ = type("VideoMAEWrap", (torch.nn.Module,), {"forward": lambda self, x: self.model(x)})
+        wrap.model = inner
+        names = synth.fill_parameters(wrap, 101)
+        pv.apply_patch(wrap, prop_attn=prop)
+        metas.append(emit(f"videomae_prop{int(prop)}", wrap, lambda: wrap._tome_info, (2, 3, 8, 32, 32), 5, pv, False,
+                          dict(host="videomae", cfg=cfgv, weight_seed=101, param_names=names), HERE, prop))
+    # ---- TimeSformer (tome/patch/timesformer.py over timesformer.py), divided space-time
+    tsm = importlib.import_module("slowfast.models.timesformer")
+    pt = importlib.import_module("tome.patch.timesformer")
+    cfgt = dict(img_size=48, patch_size=8, num_classes=10, embed_dim=32, depth=4, num_heads=2, mlp_ratio=4,
+                qkv_bias=True, num_frames=4, attention_type="divided_space_time")
+    for prop in (True, False):
+        torch.manual_seed(12)
+        inner = tsm.VisionTransformer(norm_layer=lambda d: torch.nn.LayerNorm(d, eps=1e-6), drop_path_rate=0.0,
+                                      **cfgt).eval()
+        wrap = torch.nn.Module()
+        wrap.__class__ = type("TimeSformerWrap", (torch.nn.Module,), {"forward": lambda self, x: self.model(x)})
+        wrap.model = inner
+        names = synth.fill_parameters(wrap, 202)
+        pt.apply_patch(wrap, prop_attn=prop)
+        metas.append(emit(f"timesformer_prop{int(prop)}", wrap, lambda: wrap._tome_info, (2, 3, 4, 48, 48), 6, pt,
+                          False, dict(host="timesformer", cfg=cfgt, weight_seed=202, param_names=names), HERE, prop))
+    # ---- Motionformer (tome/patch/motionformer.py over motionformer_video_model_builder.py)
+    mb = importlib.import_module("slowfast.models.motionformer_video_model_builder")
+    pm = importlib.import_module("tome.patch.motionformer")
+    mcfg = SimpleNamespace(
+        DATA=SimpleNamespace(TRAIN_CROP_SIZE=224), MODEL=SimpleNamespace(NUM_CLASSES=10),
+        EPICKITCHENS=SimpleNamespace(NUM_CLASSES=None),
+        MOTIONFORMER=SimpleNamespace(PATCH_SIZE=32, CHANNELS=3, EMBED_DIM=32, DEPTH=3, NUM_HEADS=2, MLP_RATIO=4,
+                                     QKV_BIAS=True, DROP=0.0, DROP_PATH=0.0, HEAD_DROPOUT=0.0, VIDEO_INPUT=True,
+                                     TEMPORAL_RESOLUTION=4, USE_MLP=True, ATTN_DROPOUT=0.0, HEAD_ACT="tanh",
+                                     PATCH_SIZE_TEMP=2, POS_DROPOUT=0.0, POS_EMBED="separate", ATTN_LAYER="trajectory",
+                                     USE_ORIGINAL_TRAJ_ATTN_CODE=True, APPROX_ATTN_TYPE="none", APPROX_ATTN_DIM=128))
+    cfgm = dict(img_size=224, patch_size=32, patch_size_temp=2, temporal_resolution=4, num_classes=10, embed_dim=32,
+                depth=3, num_heads=2, mlp_ratio=4.0, qkv_bias=True, use_mlp=True, head_act="tanh")
+    for prop in (True, False):
+        torch.manual_seed(13)
+        model = mb.Motionformer(mcfg).eval()
+        names = synth.fill_parameters(model, 303)  # (the reference zero-inits the tubelet conv: duplicate tokens)
+        pm.apply_patch(model, prop_attn=prop)
+        metas.append(emit(f"motionformer_prop{int(prop)}", model, lambda: model._tome_info, (2, 3, 8, 224, 224), 5, pm,
+                          False, dict(host="motionformer", cfg=cfgm, weight_seed=303, param_names=names), HERE, prop))
+    man_path = os.path.join(HERE, "manifest.json")
+    manifest = json.load(open(man_path))
+    manifest["models"] = metas
+    manifest["models_tau"] = TAU
+    with open(man_path, "w") as f:
+        json.dump(manifest, f, indent=1)
+
+
+if __name__ == "__main__":
+    main()

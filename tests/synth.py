@@ -65,3 +65,23 @@ def to_bf16_bits(a: np.ndarray) -> np.ndarray:
 def bf16_round(a: np.ndarray) -> np.ndarray:
     """fp32 array whose values are exactly representable in bf16."""
     return (to_bf16_bits(a).astype(np.uint32) << np.uint32(16)).view(np.float32).reshape(a.shape)
+
+
+def fill_parameters(module, base_seed: int, scale: float = 0.05) -> list:
+    """Overwrite every parameter of a torch module with deterministic values keyed by its NAME (sorted),
+    so two implementations with the same parameter names get bit-identical weights without shipping a
+    state_dict.  LayerNorm-like gains are set around 1, everything else around 0.  Returns the names."""
+    import zlib
+
+    import torch
+    names = []
+    with torch.no_grad():
+        for name, p in sorted(module.named_parameters(), key=lambda kv: kv[0]):
+            vals = normal_like(tuple(p.shape), base_seed + zlib.crc32(name.encode()))
+            is_gain = p.ndim == 1 and name.endswith("weight") and ("norm" in name)
+            t = torch.from_numpy(vals * np.float32(0.1 if is_gain else scale))
+            if is_gain:
+                t = t + 1.0
+            p.copy_(t.to(p.dtype))
+            names.append(name)
+    return names

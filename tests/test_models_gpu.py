@@ -1,0 +1,160 @@
+"""Patched-model parity on the GPU (`-m gpu`): this repository's host models + `tome.patch.*` (HIP merge
+path) against golden vectors of the reference's own patched models (tests/golden/generate_models.py ran
+tome/patch/{videomae,timesformer,motionformer}.py over the slowfast model files on CPU).
+
+Weights are filled by name (tests/synth.fill_parameters) on both sides, the clip comes from its seed.
+Checked per layer: token counts, r_eff, src/dst/unm indices (bit-exact: the fixtures' seeds were chosen
+so that every layer's decision margins are >= 5e-5, far above the fp32 GEMM noise between CPU and GPU);
+at the end: token sizes exactly, logits within 2e-4 (fp32 attention/MLP run on different BLAS).
+ViViT has no reference fixture (parity unpinned); it gets structural checks only.
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import golden_io as G
+import synth
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _hosts():
+    import tome  # noqa: F401
+    from hosts import motionformer, timesformer, videomae, vivit
+    return tome, dict(videomae=videomae, timesformer=timesformer, motionformer=motionformer, vivit=vivit)
+
+
+def _build(meta):
+    tome, H = _hosts()
+    cfg = dict(meta["cfg"])
+    if meta["host"] == "videomae":
+        model = H["videomae"].VideoMAE(num_frames=cfg.pop("all_frames"), num_classes=cfg.pop("num_classes"),
+                                       tubelet_size=cfg.pop("tubelet_size"), **cfg)
+        patch = tome.patch.videomae
+    elif meta["host"] == "timesformer":
+        model = H["timesformer"].TimeSformer(num_frames=cfg.pop("num_frames"), num_classes=cfg.pop("num_classes"),
+                                             attention_type=cfg.pop("attention_type"), **cfg)
+        patch = tome.patch.timesformer
+    else:
+        model = H["motionformer"].Motionformer(**cfg)
+        patch = tome.patch.motionformer
+    names = synth.fill_parameters(model, meta["weight_seed"])
+    # same parameter names as the reference model (its checkpoints load); the reference's Motionformer also
+    # carries an unused 2-D patch_embed
+    extra = set(meta["param_names"]) - set(names)
+    assert set(names) <= set(meta["param_names"]) and all(n.startswith("patch_embed.") for n in extra), extra
+    return tome, model.to(DEV).eval(), patch
+
+
+def _trace(tome, model, clip, r):
+    """Run the patched model, recording the plan of every matching."""
+    from tome.patch import _common
+    plans = []
+    orig = _common.bipartite_soft_matching
+
+    def spy(metric, r_, class_token=False, distill_token=False, mode="merge"):
+        merge, unmerge = orig(metric, r_, class_token, distill_token, mode)
+        if hasattr(merge, "plan"):
+            plans.append((metric.shape, merge.plan))
+        return merge, unmerge
+    _common.bipartite_soft_matching = spy
+    try:
+        model.r = r
+        with torch.no_grad():
+            out = model([clip])
+    finally:
+        _common.bipartite_soft_matching = orig
+    return out, plans
+
+
+@pytest.mark.parametrize("meta", G.manifest()["models"], ids=lambda m: m["name"])
+def test_patched_model_matches_reference(meta):
+    tome, model, patch = _build(meta)
+    patch(model, prop_attn=meta["prop_attn"])
+    clip = torch.from_numpy(synth.uniform01(tuple(meta["clip_shape"]), meta["seed"])).to(DEV)
+    out, plans = _trace(tome, model, clip, meta["r"])
+    z = np.load(os.path.join(G.GOLDEN, f"models_{meta['name']}.npz"))
+    assert [s[1] for s, _ in plans] == meta["tokens"]
+    assert [p.r for _, p in plans] == meta["r_eff"]
+    assert [s[0] for s, _ in plans] == meta["groups"]
+    for i, (_, p) in enumerate(plans):
+        np.testing.assert_array_equal(p.src_idx.cpu().numpy()[..., 0], z[f"L{i}_src"], err_msg=f"layer {i} src")
+        np.testing.assert_array_equal(p.dst_idx.cpu().numpy()[..., 0], z[f"L{i}_dst"], err_msg=f"layer {i} dst")
+        np.testing.assert_array_equal(p.unm_idx.cpu().numpy()[..., 0], z[f"L{i}_unm"], err_msg=f"layer {i} unm")
+    np.testing.assert_array_equal(model._tome_info["size"].cpu().numpy(), z["size"])
+    np.testing.assert_allclose(out.cpu().numpy(), z["logits"], atol=2e-4, rtol=1e-4)
+
+
+def test_videomae_schedule_and_modes():
+    """r schedules (tuple form as the drivers set it), drop / hybrid / random modes and trace_source run end
+    to end and walk the expected token counts (VideoMAE 1568 -> 1376 at r=16)."""
+    tome, H = _hosts()
+    torch.manual_seed(0)
+    model = H["videomae"].VideoMAE(num_frames=16, img_size=224, patch_size=16, embed_dim=64, depth=12, num_heads=2,
+                                   num_classes=7).to(DEV).eval()
+    clip = [torch.rand(1, 3, 16, 224, 224, device=DEV)]
+    for mode in ("merge", "drop", "hybrid", "random_merge", "random_drop"):
+        tome.patch.videomae(model, mode=mode, threshold=0.5, trace_source=(mode == "merge"))
+        model.r = (16, 0)
+        with torch.no_grad():
+            out = model(clip)
+        assert out.shape == (1, 7) and torch.isfinite(out).all()
+        size = model._tome_info["size"]
+        assert size.shape[1] == 1376
+        if mode in ("merge", "random_merge"):
+            assert float(size.sum()) == 1568.0
+        if mode == "merge":
+            src = model._tome_info["source"]
+            assert src.shape == (1, 1376, 1568) and float(src.sum()) == 1568.0
+    tome.patch.videomae(model)
+    model.r = (16, -1)  # decreasing schedule: 32, 29, ..., 2, 0
+    with torch.no_grad():
+        model(clip)
+    assert model._tome_info["size"].shape[1] == 1568 - sum([32, 29, 26, 23, 20, 17, 14, 11, 8, 5, 2, 0])
+
+
+def test_vivit_structural():
+    """ViViT: class token protected and first, token counts 3137 -> 3137 - 64*layers at reduced depth/width."""
+    tome, H = _hosts()
+    torch.manual_seed(0)
+    model = H["vivit"].ViViT(num_classes=5, image_size=224, num_frames=32, hidden_size=64, num_hidden_layers=3,
+                             num_attention_heads=2, intermediate_size=128).to(DEV).eval()
+    tome.patch.vivit(model)
+    assert model._tome_info["class_token"] is True
+    out, plans = _trace(tome, model, torch.rand(1, 3, 32, 224, 224, device=DEV), 64)
+    assert out.shape == (1, 5) and torch.isfinite(out).all()
+    assert [s[1] for s, _ in plans] == [3137, 3073, 3009]
+    for _, p in plans:
+        assert int(p.unm_idx[0, 0, 0]) == 0 and bool((p.src_idx != 0).all())
+    assert float(model._tome_info["size"].sum()) == 3137.0
+
+
+def test_timesformer_r32_walks_to_one_token():
+    """TimeSformer r=32 on 196 spatial tokens: 196,164,132,100,68,36,18,9,5,3,2,1."""
+    tome, H = _hosts()
+    torch.manual_seed(0)
+    model = H["timesformer"].TimeSformer(num_frames=2, img_size=224, patch_size=16, embed_dim=32, depth=12,
+                                         num_heads=2, num_classes=3).to(DEV).eval()
+    tome.patch.timesformer(model)
+    out, plans = _trace(tome, model, torch.rand(1, 3, 2, 224, 224, device=DEV), 32)
+    assert [s[1] for s, _ in plans] == [196, 164, 132, 100, 68, 36, 18, 9, 5, 3, 2]
+    assert [p.r for _, p in plans] == [32, 32, 32, 32, 32, 18, 9, 4, 2, 1, 1]
+    assert torch.isfinite(out).all()
+
+
+def test_duplicate_layer_patches():
+    tome, H = _hosts()
+    torch.manual_seed(0)
+    model = H["videomae"].VideoMAE(num_frames=4, img_size=32, patch_size=8, embed_dim=32, depth=3, num_heads=2,
+                                   num_classes=3).to(DEV).eval()
+    tome.patch.duplicate_videomae(model, 1, 3)
+    assert len(model.model.blocks) == 5
+    tome.patch.videomae(model)
+    model.r = [2, 2, 2, 2, 2]
+    with torch.no_grad():
+        out = model([torch.rand(2, 3, 4, 32, 32, device=DEV)])
+    assert torch.isfinite(out).all() and model._tome_info["size"].shape[1] == 32 - 10

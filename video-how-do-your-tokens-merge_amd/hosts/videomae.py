@@ -7,18 +7,20 @@ from __future__ import annotations
 
 import math
 
+import numpy as np
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
 
 def sincos_table(n_position: int, d_hid: int) -> torch.Tensor:
-    """Fixed positional table: even channels sin, odd channels cos of pos / 10000^(2*(j//2)/d)."""
-    pos = torch.arange(n_position, dtype=torch.float64)[:, None]
-    j = torch.arange(d_hid, dtype=torch.float64)[None, :]
-    angle = pos / torch.pow(torch.tensor(10000.0, dtype=torch.float64), 2 * torch.div(j, 2, rounding_mode="floor") / d_hid)
-    table = torch.where((torch.arange(d_hid) % 2 == 0)[None, :], torch.sin(angle), torch.cos(angle))
-    return table.float()[None]
+    """Fixed positional table: even channels sin, odd channels cos of pos / 10000^(2*(j//2)/d), evaluated in
+    numpy float64 and cast once (bit-identical to the table the reference's checkpoints were trained with)."""
+    j = np.arange(d_hid)
+    angle = np.arange(n_position, dtype=np.float64)[:, None] / np.power(10000, 2 * (j // 2) / d_hid)[None, :]
+    angle[:, 0::2] = np.sin(angle[:, 0::2])
+    angle[:, 1::2] = np.cos(angle[:, 1::2])
+    return torch.tensor(angle, dtype=torch.float).unsqueeze(0)
 
 
 class Mlp(nn.Module):

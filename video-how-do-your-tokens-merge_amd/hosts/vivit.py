@@ -1,0 +1,184 @@
+"""ViViT host (factorised-nothing "spatio-temporal attention" ViViT-B/16x2 as HF transformers 4.x lays it
+out and slowfast/models/vivit_video_model_builder.py:13-67 wraps it in the reference): tubelet Conv3d
+embedding, class token, learned positions, pre-LN layers, final layernorm, logits from token 0.  Module
+names follow HF's `VivitModel` (embeddings / encoder.layer[i].attention.attention.{query,key,value} / ...)
+so HF checkpoints map onto it.  Block-level parity with HF is unpinned here: the installed
+transformers no longer has the class the reference patches."""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+def gelu_fast(x):
+    return 0.5 * x * (1.0 + torch.tanh(x * 0.7978845608 * (1.0 + 0.044715 * x * x)))
+
+
+class VivitConfig:
+    def __init__(self, image_size=224, num_frames=32, tubelet_size=(2, 16, 16), num_channels=3, hidden_size=768,
+                 num_hidden_layers=12, num_attention_heads=12, intermediate_size=3072, layer_norm_eps=1e-6,
+                 qkv_bias=True):
+        self.image_size, self.num_frames, self.tubelet_size = image_size, num_frames, tuple(tubelet_size)
+        self.num_channels, self.hidden_size = num_channels, hidden_size
+        self.num_hidden_layers, self.num_attention_heads = num_hidden_layers, num_attention_heads
+        self.intermediate_size, self.layer_norm_eps, self.qkv_bias = intermediate_size, layer_norm_eps, qkv_bias
+
+
+class VivitTubeletEmbeddings(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        t, h, w = cfg.tubelet_size
+        self.num_patches = (cfg.image_size // h) * (cfg.image_size // w) * (cfg.num_frames // t)
+        self.projection = nn.Conv3d(cfg.num_channels, cfg.hidden_size, kernel_size=cfg.tubelet_size, stride=cfg.tubelet_size)
+
+    def forward(self, pixel_values):  # [B, T, C, H, W]
+        return self.projection(pixel_values.permute(0, 2, 1, 3, 4)).flatten(2).transpose(1, 2)
+
+
+class VivitEmbeddings(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.cls_token = nn.Parameter(torch.zeros(1, 1, cfg.hidden_size))
+        self.patch_embeddings = VivitTubeletEmbeddings(cfg)
+        self.position_embeddings = nn.Parameter(torch.zeros(1, self.patch_embeddings.num_patches + 1, cfg.hidden_size))
+
+    def forward(self, pixel_values):
+        x = self.patch_embeddings(pixel_values)
+        x = torch.cat((self.cls_token.expand(x.shape[0], -1, -1), x), dim=1)
+        return x + self.position_embeddings
+
+
+class VivitSelfAttention(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.num_attention_heads = cfg.num_attention_heads
+        self.attention_head_size = cfg.hidden_size // cfg.num_attention_heads
+        self.all_head_size = cfg.hidden_size
+        self.query = nn.Linear(cfg.hidden_size, cfg.hidden_size, bias=cfg.qkv_bias)
+        self.key = nn.Linear(cfg.hidden_size, cfg.hidden_size, bias=cfg.qkv_bias)
+        self.value = nn.Linear(cfg.hidden_size, cfg.hidden_size, bias=cfg.qkv_bias)
+        self.dropout = nn.Dropout(0.0)
+
+    def heads(self, x):
+        B, N, _ = x.shape
+        return x.view(B, N, self.num_attention_heads, self.attention_head_size).permute(0, 2, 1, 3)
+
+    def forward(self, hidden_states, head_mask=None, output_attentions=False):
+        q, k, v = self.heads(self.query(hidden_states)), self.heads(self.key(hidden_states)), self.heads(self.value(hidden_states))
+        ctx = F.scaled_dot_product_attention(q, k, v)
+        return (ctx.permute(0, 2, 1, 3).reshape(hidden_states.shape[0], -1, self.all_head_size),)
+
+
+class VivitSelfOutput(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.dense = nn.Linear(cfg.hidden_size, cfg.hidden_size)
+        self.dropout = nn.Dropout(0.0)
+
+    def forward(self, hidden_states, input_tensor):
+        return self.dropout(self.dense(hidden_states))  # the residual is added by the layer
+
+
+class VivitAttention(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.attention = VivitSelfAttention(cfg)
+        self.output = VivitSelfOutput(cfg)
+
+    def forward(self, hidden_states, head_mask=None, output_attentions=False):
+        return (self.output(self.attention(hidden_states)[0], hidden_states),)
+
+
+class VivitIntermediate(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.dense = nn.Linear(cfg.hidden_size, cfg.intermediate_size)
+        self.dropout = nn.Dropout(0.0)
+
+    def forward(self, hidden_states):
+        return self.dropout(gelu_fast(self.dense(hidden_states)))
+
+
+class VivitOutput(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.dense = nn.Linear(cfg.intermediate_size, cfg.hidden_size)
+        self.dropout = nn.Dropout(0.0)
+
+    def forward(self, hidden_states, input_tensor):
+        return self.dropout(self.dense(hidden_states)) + input_tensor
+
+
+class VivitLayer(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.attention = VivitAttention(cfg)
+        self.intermediate = VivitIntermediate(cfg)
+        self.output = VivitOutput(cfg)
+        self.layernorm_before = nn.LayerNorm(cfg.hidden_size, eps=cfg.layer_norm_eps)
+        self.layernorm_after = nn.LayerNorm(cfg.hidden_size, eps=cfg.layer_norm_eps)
+
+    def forward(self, hidden_states, head_mask=None, output_attentions=False):
+        hidden_states = self.attention(self.layernorm_before(hidden_states))[0] + hidden_states
+        return (self.output(self.intermediate(self.layernorm_after(hidden_states)), hidden_states),)
+
+
+class VivitEncoder(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.layer = nn.ModuleList([VivitLayer(cfg) for _ in range(cfg.num_hidden_layers)])
+
+    def forward(self, hidden_states):
+        for layer in self.layer:
+            hidden_states = layer(hidden_states)[0]
+        return hidden_states
+
+
+class VivitModel(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.config = cfg
+        self.embeddings = VivitEmbeddings(cfg)
+        self.encoder = VivitEncoder(cfg)
+        self.layernorm = nn.LayerNorm(cfg.hidden_size, eps=cfg.layer_norm_eps)
+
+    def forward(self, pixel_values):
+        return (self.layernorm(self.encoder(self.embeddings(pixel_values))),)
+
+
+class ViViT(nn.Module):
+    """Wrapper with ``.vivit`` and ``.classifier`` like slowfast's ViViT; input is the slowfast list of
+    pathways with a [B, C, T, H, W] clip."""
+
+    def __init__(self, cfg: VivitConfig = None, num_classes=400, **cfg_kwargs):
+        super().__init__()
+        self.config = cfg or VivitConfig(**cfg_kwargs)
+        self.num_labels = num_classes
+        self.vivit = VivitModel(self.config)
+        self.classifier = nn.Linear(self.config.hidden_size, num_classes)
+        self.apply(self._init)
+
+    @staticmethod
+    def _init(m):
+        if isinstance(m, (nn.Linear, nn.Conv3d)):
+            nn.init.normal_(m.weight, std=0.02)
+            if m.bias is not None:
+                nn.init.zeros_(m.bias)
+        elif isinstance(m, nn.LayerNorm):
+            nn.init.ones_(m.weight)
+            nn.init.zeros_(m.bias)
+        elif isinstance(m, VivitEmbeddings):
+            nn.init.normal_(m.cls_token, std=0.02)
+            nn.init.normal_(m.position_embeddings, std=0.02)
+
+    def forward(self, pixel_values):
+        seq = self.vivit(pixel_values[0].permute(0, 2, 1, 3, 4))[0]
+        return self.classifier(seq[:, 0, :])
+
+
+def vivit_base(num_frames=32, **kw) -> ViViT:
+    """ViViT-B/16x2: 32x224x224 clips -> 16*196 + 1 = 3137 tokens."""
+    return ViViT(num_frames=num_frames, **kw)

@@ -1,0 +1,125 @@
+"""ToMe patch for Motionformer (reference: tome/patch/motionformer.py).  Trajectory attention over
+1 + P*F tokens; the merge runs on F groups of P tokens obtained by the reference's own regrouping
+'b (s f) d -> (b f) s d' (a stride-F slicing of the frame-major token sequence -- kept as it is, SURVEY.md
+section 7.5), the class token is kept aside.  apply_patch takes the model itself."""
+from __future__ import annotations
+
+import torch
+from einops import rearrange
+
+from . import _common as C
+
+
+def _block_forward(self, x, seq_len=196, num_frames=8, approx="none", num_landmarks=128):
+    """ToMeBlock.forward (motionformer.py:15-30)."""
+    info = self._tome_info
+    attn_size = info["size"] if info["prop_attn"] else None
+    attn_out, _, metric = self.attn(self.norm1(x), seq_len=seq_len, num_frames=num_frames, approx=approx,
+                                    num_landmarks=num_landmarks, size=attn_size)
+    x = x + self.drop_path(attn_out)
+    x = self.reduction_function(metric, x, info, num_frames)
+    return x + self.drop_path(self.mlp(self.norm2(x)))
+
+
+def qkv_attn(q, k, v):
+    attn = torch.einsum("b i d, b j d -> b i j", q, k).softmax(dim=-1)
+    return torch.einsum("b i j, b j d -> b i d", attn, v)
+
+
+def _trajectory_forward(self, x, seq_len=196, num_frames=8, approx="none", num_landmarks=128,
+                        size: torch.Tensor = None):
+    """ToMeTrajectoryAttention.forward (motionformer.py:33-144), exact attention only.  P is recomputed
+    from the current token count; the size bias is added in the reference's '(s f)' order; the class
+    token's own attention ignores size; metric = head-mean of the keys regrouped '(s f) -> (b f) s'."""
+    if approx != "none":
+        raise NotImplementedError("ToMe Motionformer patch: only approx='none' (the reference's ToMe configs)")
+    B, N, _ = x.shape
+    F = num_frames
+    P = (N - 1) // F
+    h = self.num_heads
+    q, k, v = self.qkv(x).chunk(3, dim=-1)
+    q, k, v = (rearrange(t, "b n (h d) -> (b h) n d", h=h) for t in (q, k, v))
+    (cls_q, q_), (cls_k, k_), (cls_v, v_) = ((t[:, 0:1], t[:, 1:]) for t in (q, k, v))
+    cls_out = rearrange(qkv_attn(cls_q * self.scale, k, v), "(b h) f d -> b f (h d)", f=1, h=h)
+    q_dot_k = rearrange(q_ @ k_.transpose(-2, -1), "b q (f n) -> b q f n", f=F) * self.scale
+    if size is not None:
+        q_dot_k = rearrange(q_dot_k, "(b h) q f n -> b h q (f n)", h=h, f=F)
+        size_seq = rearrange(size, "(b f) s i -> b (s f) i", f=F)
+        q_dot_k = q_dot_k + size_seq.log()[:, None, None, :, 0].to(q_dot_k.dtype)
+        q_dot_k = rearrange(q_dot_k, "b h q (f n) -> (b h) q f n", h=h, f=F)
+    attn = self.attn_drop(q_dot_k.softmax(dim=-1))
+    v_ = rearrange(v_, "b (f n) d -> b f n d", f=F, n=P)
+    y = torch.einsum("b q f n, b f n d -> b q f d", attn, v_)
+    y = rearrange(y, "(b h) s f d -> b s f (h d)", b=B)
+    y_diag = rearrange(y, "b (g n) f d -> b g n f d", g=F)
+    y_diag = torch.diagonal(y_diag, dim1=-4, dim2=-2)
+    y_diag = rearrange(y_diag, "b n d f -> b (f n) d", f=F)
+    q2 = rearrange(self.proj_q(y_diag), "b s (h d) -> b h s d", h=h) * self.scale
+    k2, v2 = self.proj_kv(y).chunk(2, dim=-1)
+    k2, v2 = (rearrange(t, "b s f (h d) -> b h s f d", f=F, h=h) for t in (k2, v2))
+    tattn = torch.einsum("b h s d, b h s f d -> b h s f", q2, k2).softmax(dim=-1)
+    val = rearrange(y, "b s f (h d) -> b h s f d", f=F, h=h) if self.use_original_code else v2
+    out = rearrange(torch.einsum("b h s f, b h s f d -> b h s d", tattn, val), "b h s d -> b s (h d)")
+    out = self.proj_drop(self.proj(torch.cat((cls_out, out), dim=1)))
+    keys = rearrange(k_, "(b h) (s f) d -> (b f) h s d", f=F, h=h)
+    return out, tattn, keys.mean(1)
+
+
+def _regroup(x, num_frames):
+    return rearrange(x[:, 1:, :], "b (s f) d -> (b f) s d", f=num_frames)
+
+
+def _ungroup(cls, y, num_frames):
+    return torch.cat((cls, rearrange(y, "(b f) s d -> b (s f) d", f=num_frames)), dim=1)
+
+
+def motionformer_merge(metric, x, _tome_info, num_frames):
+    r = _tome_info["r"].pop(0)
+    if r > 0:
+        x = _ungroup(x[:, 0:1, :], C.reduce_merge(metric, _regroup(x, num_frames).contiguous(), _tome_info, r), num_frames)
+    return x
+
+
+def motionformer_drop(metric, x, _tome_info, num_frames):
+    r = _tome_info["r"].pop(0)
+    if r > 0:
+        x = _ungroup(x[:, 0:1, :], C.reduce_drop(metric, _regroup(x, num_frames).contiguous(), _tome_info, r), num_frames)
+    return x
+
+
+def motionformer_hybrid(metric, x, _tome_info, num_frames):
+    r = _tome_info["r"].pop(0)
+    if r > 0:
+        x = _ungroup(x[:, 0:1, :], C.reduce_hybrid(metric, _regroup(x, num_frames).contiguous(), _tome_info, r), num_frames)
+    return x
+
+
+def apply_duplicate_patch(model, layer_to_duplicate, quantity):
+    """motionformer.py:230-232: the same block object is visited `quantity` times."""
+    for i in range(layer_to_duplicate + 1, layer_to_duplicate + quantity):
+        model.blocks.insert(index=i, module=model.blocks[layer_to_duplicate])
+
+
+def _is_block(m) -> bool:
+    return all(hasattr(m, a) for a in ("attn", "mlp", "norm1", "norm2")) and hasattr(m.attn, "proj_kv")
+
+
+def _is_trajectory_attention(m) -> bool:
+    return all(hasattr(m, a) for a in ("qkv", "proj_q", "proj_kv", "proj", "use_original_code"))
+
+
+def apply_patch(model, trace_source: bool = False, prop_attn: bool = True, mode: str = "merge",
+                head_aggregation: str = "mean", threshold: float = 0.0, verbose: bool = False):
+    C.wrap_model_forward(model, lambda w: w.blocks)
+    model.r = 0
+    info = C.new_tome_info(trace_source, prop_attn, mode, head_aggregation, threshold, verbose, class_token=False)
+    del info["head_aggregation"]  # not part of the reference's Motionformer dict (motionformer.py:254-265)
+    model._tome_info = info
+    reduction_function = C.pick_reduction(mode, motionformer_merge, motionformer_drop, motionformer_hybrid)
+    for module in model.modules():
+        if _is_block(module):
+            C.swizzle(module, "ToMeBlock", {"forward": _block_forward})
+            module._tome_info = model._tome_info
+            module.reduction_function = reduction_function
+        elif _is_trajectory_attention(module):
+            C.swizzle(module, "ToMeTrajectoryAttention", {"forward": _trajectory_forward})

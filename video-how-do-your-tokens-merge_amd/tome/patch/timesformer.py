@@ -1,0 +1,114 @@
+"""ToMe patch for TimeSformer (reference: tome/patch/timesformer.py).  Divided space-time attention: the
+merge runs per frame on the spatial tokens ('b (p t) m -> (b t) p m'), the class token is kept aside, every
+frame loses the same r tokens so the frame groups stay rectangular."""
+from __future__ import annotations
+
+import torch
+import torch.nn.functional as F
+
+from . import _common as C
+
+
+def _block_forward(self, x, B, T, W):
+    """ToMeBlock.forward (timesformer.py:13-57)."""
+    info = self._tome_info
+    attn_size = info["size"] if info["prop_attn"] else None
+    if self.attention_type in ("space_only", "joint_space_time"):
+        x = x + self.drop_path(self.attn(self.norm1(x))[0])
+        return x + self.drop_path(self.mlp(self.norm2(x)))
+    P = (x.size(1) - 1) // T  # spatial tokens per frame right now (H and W mean nothing after merging)
+    m = x.size(2)
+    # temporal attention over the T copies of every spatial token
+    xt = x[:, 1:, :]
+    rt = self.drop_path(self.temporal_attn(self.temporal_norm1(xt.reshape(B * P, T, m)))).reshape(B, P * T, m)
+    xt = xt + self.temporal_fc(rt)
+    # spatial attention per frame, class token replicated into every frame
+    cls0 = x[:, :1, :]
+    cls = cls0.expand(B, T, m).reshape(B * T, 1, m)
+    xs = xt.reshape(B, P, T, m).transpose(1, 2).reshape(B * T, P, m)
+    rs, metric = self.attn(self.norm1(torch.cat((cls, xs), 1)), attn_size)
+    rs = self.drop_path(rs)
+    cls_new = rs[:, 0, :].reshape(B, T, m).mean(1, keepdim=True)  # class token averaged over frames
+    rs = rs[:, 1:, :].reshape(B, T, P, m).transpose(1, 2).reshape(B, P * T, m)
+    x = torch.cat((cls0, xt), 1) + torch.cat((cls_new, rs), 1)
+    x = self.reduction_function(metric, x, info, B, T, P)
+    return x + self.drop_path(self.mlp(self.norm2(x)))
+
+
+def _attention_forward(self, x, size: torch.Tensor = None):
+    """ToMeAttention.forward (timesformer.py:60-83): size bias on the non-class block of the logits only,
+    metric = head-mean of the keys without the class token."""
+    B, N, Cc = x.shape
+    if self.with_qkv:
+        q, k, v = self.qkv(x).reshape(B, N, 3, self.num_heads, Cc // self.num_heads).permute(2, 0, 3, 1, 4)
+    else:
+        q = k = v = x.reshape(B, N, self.num_heads, Cc // self.num_heads).permute(0, 2, 1, 3)
+    bias = None
+    if size is not None:
+        bias = torch.zeros(B, 1, N, N, dtype=q.dtype, device=q.device)
+        bias[:, :, 1:, 1:] = size.log()[:, None, None, :, 0].to(q.dtype)
+    drop_p = self.attn_drop.p if self.training else 0.0
+    out = F.scaled_dot_product_attention(q, k, v, attn_mask=bias, dropout_p=drop_p, scale=self.scale)
+    out = out.transpose(1, 2).reshape(B, N, Cc)
+    if self.with_qkv:
+        out = self.proj_drop(self.proj(out))
+    return out, k.mean(1)[:, 1:, :]
+
+
+def _regroup(x, B, T, P):
+    """'b (p t) m -> (b t) p m' on the tokens after the class token."""
+    return x[:, 1:, :].reshape(B, P, T, -1).transpose(1, 2).reshape(B * T, P, -1)
+
+
+def _ungroup(cls, y, B, T):
+    """'(b t) p m -> b (p t) m' and the class token back in front."""
+    P2 = y.size(1)
+    return torch.cat((cls, y.reshape(B, T, P2, -1).transpose(1, 2).reshape(B, P2 * T, -1)), dim=1)
+
+
+def timesformer_merge(metric, x, _tome_info, B, T, num_spatial_tokens):
+    r = _tome_info["r"].pop(0)
+    if r > 0:
+        x = _ungroup(x[:, 0:1, :], C.reduce_merge(metric, _regroup(x, B, T, num_spatial_tokens), _tome_info, r), B, T)
+    return x
+
+
+def timesformer_drop(metric, x, _tome_info, B, T, num_spatial_tokens):
+    r = _tome_info["r"].pop(0)
+    if r > 0:
+        x = _ungroup(x[:, 0:1, :], C.reduce_drop(metric, _regroup(x, B, T, num_spatial_tokens), _tome_info, r), B, T)
+    return x
+
+
+def timesformer_hybrid(metric, x, _tome_info, B, T, num_spatial_tokens):
+    r = _tome_info["r"].pop(0)
+    if r > 0:
+        x = _ungroup(x[:, 0:1, :], C.reduce_hybrid(metric, _regroup(x, B, T, num_spatial_tokens), _tome_info, r), B, T)
+    return x
+
+
+def apply_duplicate_patch(model, layer_to_duplicate, quantity):
+    """timesformer.py:170-172: the same block object is visited `quantity` times."""
+    for i in range(layer_to_duplicate + 1, layer_to_duplicate + quantity):
+        model.model.blocks.insert(index=i, module=model.model.blocks[layer_to_duplicate])
+
+
+def _is_block(m) -> bool:
+    return all(hasattr(m, a) for a in ("attn", "mlp", "norm1", "norm2", "attention_type"))
+
+
+def apply_patch(model_wrapper, trace_source: bool = False, prop_attn: bool = True, mode: str = "merge",
+                head_aggregation: str = "mean", threshold: float = 0.0, verbose: bool = False):
+    model = model_wrapper.model
+    C.wrap_model_forward(model_wrapper, lambda w: w.model.blocks)
+    model_wrapper.r = 0
+    info = C.new_tome_info(trace_source, prop_attn, mode, head_aggregation, threshold, verbose, class_token=False)
+    del info["head_aggregation"]  # the reference's TimeSformer dict has no such key (timesformer.py:194-205)
+    model_wrapper._tome_info = info
+    reduction_function = C.pick_reduction(mode, timesformer_merge, timesformer_drop, timesformer_hybrid)
+    for module in model.modules():
+        if _is_block(module):
+            C.swizzle(module, "ToMeBlock", {"forward": _block_forward})
+            module._tome_info = model_wrapper._tome_info
+            module.reduction_function = reduction_function
+            C.swizzle(module.attn, "ToMeAttention", {"forward": _attention_forward})

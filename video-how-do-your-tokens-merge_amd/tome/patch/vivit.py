@@ -1,0 +1,133 @@
+"""ToMe patch for ViViT (reference: tome/patch/vivit.py).  One joint sequence with a class token
+(class_token=True: token 0 is never merged and unm_idx stays position-sorted).  apply_patch takes the
+wrapper whose ``.vivit`` is the HF-style model (``.vivit.encoder.layer``)."""
+from __future__ import annotations
+
+import copy
+import math
+
+import torch
+import torch.nn.functional as F
+
+from . import _common as C
+
+
+def _layer_forward(self, hidden_states, head_mask=None, output_attentions=False):
+    """ToMeVivitLayer.forward (vivit.py:18-47)."""
+    info = self._tome_info
+    attn_size = info["size"] if info["prop_attn"] else None
+    outs = self.attention(self.layernorm_before(hidden_states), attn_size, info["head_aggregation"], head_mask,
+                          output_attentions=output_attentions)
+    attention_output, metric, rest = outs[0], outs[1], outs[2:]
+    hidden_states = attention_output + hidden_states
+    hidden_states = self.reduction_function(metric, hidden_states, info)
+    layer_output = self.intermediate(self.layernorm_after(hidden_states))
+    layer_output = self.output(layer_output, hidden_states)  # second residual inside
+    return (layer_output,) + rest
+
+
+def _duplicate_layer_forward(self, hidden_states, head_mask=None, output_attentions=False):
+    """ToMeDuplicateVivitLayer.forward (vivit.py:50-66): attend for the metric only, then merge."""
+    info = self._tome_info
+    attn_size = info["size"] if info["prop_attn"] else None
+    outs = self.attention(self.layernorm_before(hidden_states), attn_size, info["head_aggregation"], head_mask,
+                          output_attentions=output_attentions)
+    return [self.reduction_function(outs[1], hidden_states, info)]
+
+
+def _attention_forward(self, hidden_states, size=None, head_aggregation="mean", head_mask=None,
+                       output_attentions=False):
+    """ToMeVivitAttention.forward (vivit.py:69-83)."""
+    self_outputs = self.attention(hidden_states, size, head_aggregation, head_mask, output_attentions)
+    attention_output = self.output(self_outputs[0], hidden_states)
+    return (attention_output, self_outputs[1]) + self_outputs[2:]
+
+
+def _self_attention_forward(self, hidden_states, size=None, head_aggregation="mean", head_mask=None,
+                            output_attentions=False):
+    """ToMeVivitSelfAttention.forward (vivit.py:86-130): log(size) bias on the keys, metric from the keys
+    (class-token row included)."""
+    B, N, _ = hidden_states.shape
+    H, hd = self.num_attention_heads, self.attention_head_size
+
+    def heads(t):
+        return t.view(B, N, H, hd).permute(0, 2, 1, 3)
+
+    q, k, v = heads(self.query(hidden_states)), heads(self.key(hidden_states)), heads(self.value(hidden_states))
+    bias = None if size is None else size.log()[:, None, None, :, 0].to(q.dtype)
+    probs = None
+    if output_attentions or head_mask is not None:
+        scores = torch.matmul(q, k.transpose(-1, -2)) / math.sqrt(hd)
+        if bias is not None:
+            scores = scores + bias
+        probs = self.dropout(F.softmax(scores, dim=-1))
+        if head_mask is not None:
+            probs = probs * head_mask
+        ctx = torch.matmul(probs, v)
+    else:
+        drop_p = self.dropout.p if self.training else 0.0
+        ctx = F.scaled_dot_product_attention(q, k, v, attn_mask=bias, dropout_p=drop_p)
+    ctx = ctx.permute(0, 2, 1, 3).reshape(B, N, H * hd)
+    if head_aggregation == "mean":
+        metric = k.mean(1)
+    elif head_aggregation == "concat":
+        metric = k.transpose(1, 2).reshape(B, N, -1)
+    else:
+        raise ValueError(f"head_aggregation {head_aggregation!r}")
+    return (ctx, metric, probs) if output_attentions else (ctx, metric)
+
+
+def vivit_merge(metric, x, _tome_info):
+    r = _tome_info["r"].pop(0)
+    return C.reduce_merge(metric, x, _tome_info, r) if r > 0 else x
+
+
+def vivit_drop(metric, x, _tome_info):
+    r = _tome_info["r"].pop(0)
+    return C.reduce_drop(metric, x, _tome_info, r) if r > 0 else x
+
+
+def vivit_hybrid(metric, x, _tome_info):
+    r = _tome_info["r"].pop(0)
+    return C.reduce_hybrid(metric, x, _tome_info, r) if r > 0 else x
+
+
+def _is_layer(m) -> bool:
+    return all(hasattr(m, a) for a in ("attention", "intermediate", "output", "layernorm_before", "layernorm_after"))
+
+
+def _is_attention(m) -> bool:
+    return hasattr(m, "attention") and hasattr(m, "output") and hasattr(m.attention, "query")
+
+
+def _is_self_attention(m) -> bool:
+    return all(hasattr(m, a) for a in ("query", "key", "value", "num_attention_heads", "attention_head_size"))
+
+
+def apply_duplicate_patch(model, layer_to_duplicate, quantity):
+    """vivit.py:207-211: insert deep copies that only attend + merge."""
+    for i in range(layer_to_duplicate, layer_to_duplicate + quantity - 1):
+        model.vivit.encoder.layer.insert(index=i, module=copy.deepcopy(model.vivit.encoder.layer[i]))
+        C.swizzle(model.vivit.encoder.layer[i], "ToMeDuplicateVivitLayer", {"forward": _duplicate_layer_forward})
+
+
+def apply_patch(model_wrapper, trace_source: bool = False, prop_attn: bool = True, mode: str = "merge",
+                head_aggregation: str = "mean", threshold: float = 0.0, verbose: bool = False):
+    model = model_wrapper.vivit
+    C.wrap_model_forward(model_wrapper, lambda w: w.vivit.encoder.layer)
+    model_wrapper.r = 0
+    model_wrapper._tome_info = C.new_tome_info(trace_source, prop_attn, mode, head_aggregation, threshold, verbose,
+                                               class_token=model.embeddings.cls_token is not None)
+    reduction_function = C.pick_reduction(mode, vivit_merge, vivit_drop, vivit_hybrid)
+    for module in model.modules():
+        if C.has_tag(module, "ToMeDuplicateVivitLayer"):
+            module._tome_info = model_wrapper._tome_info
+            module.reduction_function = reduction_function
+        elif _is_layer(module):
+            C.swizzle(module, "ToMeVivitLayer", {"forward": _layer_forward})
+            module._tome_info = model_wrapper._tome_info
+            module.reduction_function = reduction_function
+        elif _is_attention(module):
+            C.swizzle(module, "ToMeVivitAttention", {"forward": _attention_forward})
+        elif _is_self_attention(module):
+            C.swizzle(module, "ToMeVivitSelfAttention", {"forward": _self_attention_forward})
