@@ -101,6 +101,21 @@ int tome_merge_wavg(const void *x, int x_dtype, const void *size, int size_dtype
                     const int64_t *dst_idx, const int64_t *unm_idx, int distill_token,
                     const uint8_t *edge_keep, void *x_out, void *size_out, tome_stream_t stream);
 
+/*
+ * tome_merge_wavg_regrouped  <-  the rearrange / merge_wavg / rearrange / cat sequence of
+ *     timesformer_merge (tome/patch/timesformer.py:89-107) and motionformer_merge
+ *     (tome/patch/motionformer.py:150-168), without the two permuted copies of x.
+ *
+ * x [B, has_cls + P*F, C]: token `has_cls + p*F + f` of clip b belongs to merge group b*F + f (n = B*F groups
+ * of P tokens, the layout both patches regroup into); the index buffers and size [n,P] / size_out [n,P-r]
+ * are those of the n groups.  x_out [B, has_cls + (P-r)*F, C] in the same interleaved layout, class token
+ * rows copied through.  Arithmetic as tome_merge_wavg.  C * sizeof(dtype) must be a multiple of 16.
+ */
+int tome_merge_wavg_regrouped(const void *x, int x_dtype, const void *size, int size_dtype, int64_t B,
+                              int64_t F, int64_t P, int64_t C, int64_t r, int has_cls,
+                              const int64_t *src_idx, const int64_t *dst_idx, const int64_t *unm_idx,
+                              const uint8_t *edge_keep, void *x_out, void *size_out, tome_stream_t stream);
+
 /* tome_merge  <-  merge(x, mode) closure (merge.py:75-85; hybrid :313-334 when edge_keep). */
 int tome_merge(const void *x, int dtype, int64_t n, int64_t T, int64_t C, int64_t r,
                const int64_t *src_idx, const int64_t *dst_idx, const int64_t *unm_idx,

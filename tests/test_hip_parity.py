@@ -296,3 +296,28 @@ def test_errors_are_loud():
         merge(torch.randn(2, 15, 8, device=DEV))  # wrong token count
     with pytest.raises(TomeHipError):
         merge(torch.randn(2, 16, 8, device=DEV), mode="median")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,F,P,C,r", [(2, 4, 36, 32, 6), (3, 8, 196, 768, 16), (1, 8, 49, 64, 24), (2, 2, 9, 8, 4)])
+def test_merge_wavg_regrouped_equals_rearranged(B, F, P, C, r, dtype):
+    """tome_merge_wavg_regrouped == rearrange -> merge_wavg -> rearrange -> cat (timesformer.py:89-107,
+    motionformer.py:150-168), bit for bit, including chained sizes."""
+    from tome import _abi
+    tm = _tome()
+    seed = 900 + B * F + P
+    x_full = dev(synth.normal_like((B, 1 + P * F, C), seed), dtype)
+    size = None
+    Pc = P
+    for layer in range(2):
+        metric = dev(synth.normal_like((B * F, Pc, 16), seed + 17 * layer))
+        merge, _ = tm.bipartite_soft_matching(metric, r)
+        plan = merge.plan
+        grouped = x_full[:, 1:, :].reshape(B, Pc, F, C).transpose(1, 2).reshape(B * F, Pc, C)
+        want_x, want_s = tm.merge_wavg(merge, grouped, size)
+        P2 = Pc - plan.r
+        want_full = torch.cat((x_full[:, :1, :], want_x.reshape(B, F, P2, C).transpose(1, 2).reshape(B, P2 * F, C)), 1)
+        got_full, got_s = _abi.merge_wavg_regrouped(plan, x_full, size, F, has_cls=True)
+        assert torch.equal(got_full, want_full)
+        assert torch.equal(got_s, want_s)
+        x_full, size, Pc = got_full, got_s, P2

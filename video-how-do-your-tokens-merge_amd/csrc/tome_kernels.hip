@@ -527,15 +527,28 @@ template <int OP> __device__ __forceinline__ float reduce_step(float acc, float 
     return acc;
 }
 
+// Where the token rows of group g live.  Contiguous [n,T,C] is {0, T*C, 0, C, 1}; the regrouped views of
+// TimeSformer / Motionformer ('b (p t) m -> (b t) p m', timesformer.py:89-90; 'b (s f) d -> (b f) s d',
+// motionformer.py:150-151) are {cls*C, (cls+P*F)*C, C, F*C, F}: no permuted copy of x is ever made.
+struct TokLayout {
+    int64_t base, outer_stride, inner_stride, tok_stride;  // elements
+    int inner;                                             // groups per outer index
+};
+
+template <typename TX> __device__ __forceinline__ TX *group_ptr(TX *p, const TokLayout &L, int g) {
+    return p + L.base + (int64_t)(g / L.inner) * L.outer_stride + (int64_t)(g % L.inner) * L.inner_stride;
+}
+
 // One destination row (odd token 2j+1 plus every source merged into it), whole wave, contract order:
 // own term first, then the sources in src_idx (rank) order found by ballot-scanning dst_idx.
 template <typename TX, typename TS, int VEC, int OP>
-__device__ __forceinline__ void merge_dst_row(const TX *__restrict__ xg, const TS *__restrict__ sg, int C, int r,
-                                              int g, int j, const int64_t *__restrict__ srcg,
+__device__ __forceinline__ void merge_dst_row(const TX *__restrict__ xg, const TS *__restrict__ sg, int C,
+                                              int64_t tstride, int r, int g, int j,
+                                              const int64_t *__restrict__ srcg,
                                               const int64_t *__restrict__ dstg, const uint8_t *__restrict__ keep,
                                               TX *__restrict__ orow, TS *__restrict__ srow, int lane) {
     const int t = 2 * j + 1;
-    const TX *xr = xg + (int64_t)t * C;
+    const TX *xr = xg + (int64_t)t * tstride;
     float s_own = 1.0f;
     if (OP == OP_WAVG) s_own = sg ? to_f32(sg[t]) : 1.0f;
 
@@ -589,7 +602,7 @@ __device__ __forceinline__ void merge_dst_row(const TX *__restrict__ xg, const T
                     if (OP == OP_WAVG) s2 = sg ? to_f32(sg[ts]) : 1.0f;
                     if (act) {
                         float v[VEC];
-                        load_pack<TX, VEC>(xg + (int64_t)ts * C + c, v);
+                        load_pack<TX, VEC>(xg + (int64_t)ts * tstride + c, v);
 #pragma unroll
                         for (int e = 0; e < VEC; ++e) {
                             float p = (OP == OP_WAVG) ? __fmul_rn(v[e], s2) : v[e];
@@ -641,7 +654,7 @@ __global__ __launch_bounds__(256) void k_merge_rows(const TX *__restrict__ x, co
                                                     const int64_t *__restrict__ dst_idx,
                                                     const int64_t *__restrict__ unm_idx, int distill,
                                                     const uint8_t *__restrict__ keep, TX *__restrict__ xout,
-                                                    TS *__restrict__ sout) {
+                                                    TS *__restrict__ sout, TokLayout lin, TokLayout lout) {
     const int lane = threadIdx.x & 63;
     const int To = T_ - r;
     const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -653,12 +666,12 @@ __global__ __launch_bounds__(256) void k_merge_rows(const TX *__restrict__ x, co
     int idx;
     decode_out_row(o, U, distill, is_dst, idx);
 
-    const TX *xg = x + (int64_t)g * T_ * C;
+    const TX *xg = group_ptr(x, lin, g);
     const TS *sg = size ? size + (int64_t)g * T_ : nullptr;
-    TX *orow = xout + row * C;
+    TX *orow = group_ptr(xout, lout, g) + (int64_t)o * lout.tok_stride;
     if (!is_dst) {
         const int t = 2 * (int)unm_idx[(int64_t)g * U + idx];
-        const TX *xr = xg + (int64_t)t * C;
+        const TX *xr = xg + (int64_t)t * lin.tok_stride;
         float s = 1.0f;
         if (OP == OP_WAVG) s = sg ? to_f32(sg[t]) : 1.0f;
         for (int c = lane * VEC; c < C; c += WAVE * VEC) {
@@ -673,7 +686,7 @@ __global__ __launch_bounds__(256) void k_merge_rows(const TX *__restrict__ x, co
         if (OP == OP_WAVG && lane == 0) sout[row] = from_f32<TS>(s);
         return;
     }
-    merge_dst_row<TX, TS, VEC, OP>(xg, sg, C, r, g, idx, src_idx ? src_idx + (int64_t)g * r : nullptr,
+    merge_dst_row<TX, TS, VEC, OP>(xg, sg, C, lin.tok_stride, r, g, idx, src_idx ? src_idx + (int64_t)g * r : nullptr,
                                    dst_idx ? dst_idx + (int64_t)g * r : nullptr, keep, orow,
                                    sout ? sout + row : nullptr, lane);
 }
@@ -696,17 +709,28 @@ __global__ __launch_bounds__(256) void k_merge_rows_fast(const TX *__restrict__ 
                                                          const int64_t *__restrict__ dst_idx,
                                                          const int64_t *__restrict__ unm_idx, int distill,
                                                          const uint8_t *__restrict__ keep, TX *__restrict__ xout,
-                                                         TS *__restrict__ sout) {
+                                                         TS *__restrict__ sout, TokLayout lin, TokLayout lout,
+                                                         int cls_rows) {
     constexpr int VEC = 16 / sizeof(TX);
     const int lane = threadIdx.x & 63;
     const int To = T_ - r;
     const int rg_per_group = (To + R - 1) / R;
     const int64_t w = (int64_t)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if (w >= (int64_t)n * rg_per_group) return;
+    if (w >= (int64_t)n * rg_per_group) {
+        // the class tokens kept aside by the regrouped callers (timesformer.py:89,107): plain row copies
+        const int64_t b = w - (int64_t)n * rg_per_group;
+        if (b < cls_rows) {
+            const uint4 *src = reinterpret_cast<const uint4 *>(x + b * lin.outer_stride);
+            uint4 *dst = reinterpret_cast<uint4 *>(xout + b * lout.outer_stride);
+            for (int c = lane; c < cpr; c += WAVE) dst[c] = src[c];
+        }
+        return;
+    }
     const int g = (int)(w / rg_per_group);
     const int o0 = (int)(w - (int64_t)g * rg_per_group) * R;
     const int T1 = (T_ + 1) >> 1, U = T1 - r;
-    const TX *xg = x + (int64_t)g * T_ * C;
+    const TX *xg = group_ptr(x, lin, g);
+    TX *og = group_ptr(xout, lout, g);
     const TS *sg = size ? size + (int64_t)g * T_ : nullptr;
     const int64_t *srcg = src_idx ? src_idx + (int64_t)g * r : nullptr;
     const int64_t *dstg = dst_idx ? dst_idx + (int64_t)g * r : nullptr;
@@ -767,9 +791,10 @@ __global__ __launch_bounds__(256) void k_merge_rows_fast(const TX *__restrict__ 
         const int t = rr == 0 ? tok0 : (rr == 1 ? tok1 : (rr == 2 ? tok2 : tok3));
         const bool ok = (rr == 0 ? ok0 : (rr == 1 ? ok1 : (rr == 2 ? ok2 : ok3))) && (q < total);
         rowof[it] = ok ? rr : -1;
-        if (ok) raw[it] = *reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(xg + (int64_t)t * C) + cc * 16);
+        if (ok)
+            raw[it] = *reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(xg + (int64_t)t * lin.tok_stride) +
+                                                       cc * 16);
     }
-    char *obase = reinterpret_cast<char *>(xout + ((int64_t)g * To + o0) * C);
     // (x*s)/s is x itself when s is 1, and also when s is a power of two and x came from a 16-bit
     // format (the fp32 product cannot overflow): those rows move as raw bits
     constexpr bool narrow = sizeof(TX) == 2;
@@ -791,7 +816,8 @@ __global__ __launch_bounds__(256) void k_merge_rows_fast(const TX *__restrict__ 
                 __builtin_memcpy(&outv, &pk, 16);
             }
         }
-        *reinterpret_cast<uint4 *>(obase + (int64_t)q * 16) = outv;
+        const int cc = q - rr * cpr;
+        *reinterpret_cast<uint4 *>(reinterpret_cast<char *>(og + (int64_t)(o0 + rr) * lout.tok_stride) + cc * 16) = outv;
     }
     if (OP == OP_WAVG && lane < R && my_valid) {
         const bool mine_has_edges = lane == 0 ? e0 : (lane == 1 ? e1 : (lane == 2 ? e2 : e3));
@@ -799,16 +825,20 @@ __global__ __launch_bounds__(256) void k_merge_rows_fast(const TX *__restrict__ 
     }
     // rows that receive sources: sequential weighted sum in the contract's order
     if ((vmask & 1ull) && e0)
-        merge_dst_row<TX, TS, VEC, OP>(xg, sg, C, r, g, j0, srcg, dstg, keep, xout + ((int64_t)g * To + o0) * C,
+        merge_dst_row<TX, TS, VEC, OP>(xg, sg, C, lin.tok_stride, r, g, j0, srcg, dstg, keep,
+                                       og + (int64_t)(o0) * lout.tok_stride,
                                        sout ? sout + (int64_t)g * To + o0 : nullptr, lane);
     if ((vmask & 2ull) && e1)
-        merge_dst_row<TX, TS, VEC, OP>(xg, sg, C, r, g, j1, srcg, dstg, keep, xout + ((int64_t)g * To + o0 + 1) * C,
+        merge_dst_row<TX, TS, VEC, OP>(xg, sg, C, lin.tok_stride, r, g, j1, srcg, dstg, keep,
+                                       og + (int64_t)(o0 + 1) * lout.tok_stride,
                                        sout ? sout + (int64_t)g * To + o0 + 1 : nullptr, lane);
     if ((vmask & 4ull) && e2)
-        merge_dst_row<TX, TS, VEC, OP>(xg, sg, C, r, g, j2, srcg, dstg, keep, xout + ((int64_t)g * To + o0 + 2) * C,
+        merge_dst_row<TX, TS, VEC, OP>(xg, sg, C, lin.tok_stride, r, g, j2, srcg, dstg, keep,
+                                       og + (int64_t)(o0 + 2) * lout.tok_stride,
                                        sout ? sout + (int64_t)g * To + o0 + 2 : nullptr, lane);
     if ((vmask & 8ull) && e3)
-        merge_dst_row<TX, TS, VEC, OP>(xg, sg, C, r, g, j3, srcg, dstg, keep, xout + ((int64_t)g * To + o0 + 3) * C,
+        merge_dst_row<TX, TS, VEC, OP>(xg, sg, C, lin.tok_stride, r, g, j3, srcg, dstg, keep,
+                                       og + (int64_t)(o0 + 3) * lout.tok_stride,
                                        sout ? sout + (int64_t)g * To + o0 + 3 : nullptr, lane);
 }
 
@@ -1126,33 +1156,39 @@ extern "C" int tome_edge_keep(const float *node_max, const int64_t *src_idx, int
 
 static inline bool aligned16(const void *p) { return ((uintptr_t)p & 15) == 0; }
 
+static TokLayout contiguous_layout(int64_t T, int64_t C) { return TokLayout{0, T * C, 0, C, 1}; }
+
 template <typename TX, typename TS, int OP>
 static int launch_merge_rows(const void *x, const void *size, int64_t n, int64_t T, int64_t C, int64_t r,
                              const int64_t *src, const int64_t *dst, const int64_t *unm, int distill,
-                             const uint8_t *keep, void *xout, void *sout, hipStream_t st) {
+                             const uint8_t *keep, void *xout, void *sout, hipStream_t st,
+                             const TokLayout *lin_p = nullptr, const TokLayout *lout_p = nullptr, int cls_rows = 0) {
     constexpr int VEC = 16 / sizeof(TX);
     const int64_t To = T - r;
+    const TokLayout lin = lin_p ? *lin_p : contiguous_layout(T, C);
+    const TokLayout lout = lout_p ? *lout_p : contiguous_layout(To, C);
     const bool vec_ok = (C % VEC == 0) && aligned16(x) && aligned16(xout);
     const int64_t cpr = C / VEC;  // 16-byte chunks per row
     if (vec_ok && cpr <= FAST_NIT * WAVE) {
         int R = (int)((FAST_NIT * WAVE) / cpr);
         if (R > FAST_MAXR) R = FAST_MAXR;
-        const int64_t waves = n * ((To + R - 1) / R);
+        const int64_t waves = n * ((To + R - 1) / R) + cls_rows;
         hipLaunchKernelGGL((k_merge_rows_fast<TX, TS, OP>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st,
                            (const TX *)x, (const TS *)size, (int)n, (int)T, (int)C, (int)r, R, (int)cpr, src, dst, unm,
-                           distill, keep, (TX *)xout, (TS *)sout);
+                           distill, keep, (TX *)xout, (TS *)sout, lin, lout, cls_rows);
         return check_launch("k_merge_rows_fast");
     }
+    if (cls_rows) return fail(TOME_EINVAL, "regrouped merge needs rows of whole 16-byte chunks (C=%lld)", (long long)C);
     const int64_t rows = n * To;
     const unsigned nb = (unsigned)((rows + 3) / 4);
     if (vec_ok)
         hipLaunchKernelGGL((k_merge_rows<TX, TS, VEC, OP>), dim3(nb), dim3(256), 0, st, (const TX *)x,
                            (const TS *)size, (int)n, (int)T, (int)C, (int)r, src, dst, unm, distill, keep, (TX *)xout,
-                           (TS *)sout);
+                           (TS *)sout, lin, lout);
     else
         hipLaunchKernelGGL((k_merge_rows<TX, TS, 1, OP>), dim3(nb), dim3(256), 0, st, (const TX *)x,
                            (const TS *)size, (int)n, (int)T, (int)C, (int)r, src, dst, unm, distill, keep, (TX *)xout,
-                           (TS *)sout);
+                           (TS *)sout, lin, lout);
     return check_launch("k_merge_rows");
 }
 
@@ -1182,6 +1218,32 @@ extern "C" int tome_merge_wavg(const void *x, int x_dtype, const void *size, int
     if (x_dtype == TOME_F16 && size_dtype == TOME_F32) WAVG(f16_t, float);
 #undef WAVG
     return fail(TOME_EINVAL, "tome_merge_wavg: unsupported dtypes x=%d size=%d", x_dtype, size_dtype);
+}
+
+extern "C" int tome_merge_wavg_regrouped(const void *x, int x_dtype, const void *size, int size_dtype, int64_t B,
+                                         int64_t F, int64_t P, int64_t C, int64_t r, int has_cls,
+                                         const int64_t *src_idx, const int64_t *dst_idx, const int64_t *unm_idx,
+                                         const uint8_t *edge_keep, void *x_out, void *size_out,
+                                         tome_stream_t stream) {
+    if (B <= 0 || F <= 0) return fail(TOME_EINVAL, "tome_merge_wavg_regrouped: bad shape");
+    const int64_t n = B * F;
+    if (int rc = check_merge_args("tome_merge_wavg_regrouped", x, n, P, C, r, x_out)) return rc;
+    if (!src_idx || !dst_idx || (!unm_idx && (P + 1) / 2 > r) || !size_out)
+        return fail(TOME_EINVAL, "tome_merge_wavg_regrouped: null buffer");
+    const int cls = has_cls ? 1 : 0;
+    const TokLayout lin{cls * C, (cls + P * F) * C, C, F * C, (int)F};
+    const TokLayout lout{cls * C, (cls + (P - r) * F) * C, C, F * C, (int)F};
+    hipStream_t st = (hipStream_t)stream;
+#define WAVGR(TX, TS)                                                                                         \
+    return launch_merge_rows<TX, TS, OP_WAVG>(x, size, n, P, C, r, src_idx, dst_idx, unm_idx, 0, edge_keep, x_out, \
+                                              size_out, st, &lin, &lout, cls ? (int)B : 0)
+    if (x_dtype == TOME_F32 && size_dtype == TOME_F32) WAVGR(float, float);
+    if (x_dtype == TOME_BF16 && size_dtype == TOME_BF16) WAVGR(bf16_t, bf16_t);
+    if (x_dtype == TOME_BF16 && size_dtype == TOME_F32) WAVGR(bf16_t, float);
+    if (x_dtype == TOME_F16 && size_dtype == TOME_F16) WAVGR(f16_t, f16_t);
+    if (x_dtype == TOME_F16 && size_dtype == TOME_F32) WAVGR(f16_t, float);
+#undef WAVGR
+    return fail(TOME_EINVAL, "tome_merge_wavg_regrouped: unsupported dtypes x=%d size=%d", x_dtype, size_dtype);
 }
 
 template <typename TX>

@@ -16,7 +16,8 @@ LIB_PATH = os.environ.get("TOME_HIP_LIB", os.path.join(_PKG, "lib", "libtome_hip
 
 SYMBOLS = (
     "tome_abi_version", "tome_last_error", "tome_effective_r", "tome_match_workspace_bytes", "tome_match",
-    "tome_match_scores", "tome_edge_keep", "tome_merge_wavg", "tome_merge", "tome_drop", "tome_unmerge",
+    "tome_match_scores", "tome_edge_keep", "tome_merge_wavg", "tome_merge_wavg_regrouped", "tome_merge", "tome_drop",
+    "tome_unmerge",
     "tome_profile_enable", "tome_profile_read",
 )
 
@@ -59,6 +60,8 @@ def lib() -> ctypes.CDLL:
     L.tome_edge_keep.argtypes = [vp, vp, i64, i64, i64, ctypes.c_float, vp, vp]
     L.tome_merge_wavg.restype = i32
     L.tome_merge_wavg.argtypes = [vp, i32, vp, i32, i64, i64, i64, i64, vp, vp, vp, i32, vp, vp, vp, vp]
+    L.tome_merge_wavg_regrouped.restype = i32
+    L.tome_merge_wavg_regrouped.argtypes = [vp, i32, vp, i32, i64, i64, i64, i64, i64, i32, vp, vp, vp, vp, vp, vp, vp]
     L.tome_merge.restype = i32
     L.tome_merge.argtypes = [vp, i32, i64, i64, i64, i64, vp, vp, vp, i32, i32, vp, vp, vp]
     L.tome_drop.restype = i32
@@ -242,6 +245,46 @@ def merge_wavg(plan: MatchPlan, x: torch.Tensor, size: Optional[torch.Tensor]):
                                    plan.dst_idx.data_ptr(), plan.unm_idx.data_ptr(), int(plan.distill_token),
                                    _ptr(plan.edge_keep), x_out.data_ptr(), s_out.data_ptr(), _stream(x.device))
     _check(rc, "tome_merge_wavg")
+    return x_out, s_out
+
+
+def merge_wavg_regrouped(plan: MatchPlan, x_full: torch.Tensor, size: Optional[torch.Tensor], frames: int,
+                         has_cls: bool = True):
+    """merge_wavg on the interleaved layout of TimeSformer / Motionformer: x_full [B, has_cls + P*F, C] whose
+    token has_cls + p*F + f belongs to group b*F + f; returns x_out [B, has_cls + (P-r)*F, C] and size
+    [B*F, P-r, 1].  Replaces rearrange -> merge_wavg -> rearrange -> cat (timesformer.py:89-107)."""
+    require_device(x_full, "merge_wavg_regrouped(x)")
+    if x_full.dim() != 3:
+        raise TomeHipError(f"merge_wavg_regrouped: x must be [B, tokens, C], got {tuple(x_full.shape)}")
+    B, N, C = x_full.shape
+    cls = 1 if has_cls else 0
+    F, P = int(frames), plan.T
+    if N != cls + P * F or plan.n != B * F:
+        raise TomeHipError(f"merge_wavg_regrouped: x {tuple(x_full.shape)} does not hold {plan.n} groups of {P} "
+                           f"tokens ({F} per clip) plus {cls} class token")
+    if x_full.device != plan.device:
+        raise TomeHipError("merge_wavg_regrouped: tensor and matching on different devices")
+    if torch.is_grad_enabled() and x_full.requires_grad:
+        raise TomeHipError("merge_wavg_regrouped: autograd through the HIP merge kernels is not implemented")
+    x_full = x_full if x_full.is_contiguous() else x_full.contiguous()
+    xcode = dtype_code(x_full, "x")
+    if size is not None:
+        if size.shape != (plan.n, P, 1):
+            raise TomeHipError(f"size must be [{plan.n}, {P}, 1], got {tuple(size.shape)}")
+        if size.dtype not in (x_full.dtype, torch.float32):
+            size = size.to(x_full.dtype)
+        size = size.contiguous()
+        sdtype = size.dtype
+    else:
+        sdtype = x_full.dtype
+    x_out = torch.empty((B, cls + (P - plan.r) * F, C), dtype=x_full.dtype, device=x_full.device)
+    s_out = torch.empty((plan.n, P - plan.r, 1), dtype=sdtype, device=x_full.device)
+    with torch.cuda.device(x_full.device):
+        rc = lib().tome_merge_wavg_regrouped(x_full.data_ptr(), xcode, _ptr(size), DTYPES[sdtype], B, F, P, C, plan.r,
+                                             cls, plan.src_idx.data_ptr(), plan.dst_idx.data_ptr(),
+                                             plan.unm_idx.data_ptr(), _ptr(plan.edge_keep), x_out.data_ptr(),
+                                             s_out.data_ptr(), _stream(x_full.device))
+    _check(rc, "tome_merge_wavg_regrouped")
     return x_out, s_out
 
 

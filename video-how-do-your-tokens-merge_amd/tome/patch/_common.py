@@ -91,6 +91,29 @@ def reduce_merge(metric, x, info, r):
     return x
 
 
+def reduce_merge_regrouped(metric, x_full, info, r, frames, hybrid=False):
+    """reduce_merge / reduce_hybrid for the models whose merge groups are interleaved in the token sequence
+    (TimeSformer '(p t)', Motionformer '(s f)'): x_full is [B, 1 + P*F, C] with the class token in front; the
+    kernel addresses the groups in place and returns [B, 1 + (P-r)*F, C] (no permuted copies of x)."""
+    from .. import _abi
+    from ..merge import do_nothing
+    if hybrid:
+        merge, _ = bipartite_soft_matching_hybrid(metric, r, info["class_token"], info["distill_token"], info["mode"],
+                                                  info["threshold"])
+    else:
+        merge, _ = bipartite_soft_matching(metric, r, info["class_token"], info["distill_token"], info["mode"])
+    if merge is do_nothing:
+        return x_full
+    plan = merge.plan
+    if info["trace_source"]:
+        shape_only = x_full.new_empty((plan.n, plan.T, 0))
+        info["source"] = merge_source(merge, shape_only, info["source"])
+    x_out, info["size"] = _abi.merge_wavg_regrouped(plan, x_full, info["size"], frames, has_cls=True)
+    if info["verbose"]:
+        print(f"Merged {plan.T} to {plan.T - plan.r} tokens")
+    return x_out
+
+
 def reduce_drop(metric, x, info, r):
     drop = bipartite_soft_matching_drop(metric, r, info["class_token"], info["distill_token"], info["mode"])
     if isinstance(drop, tuple):  # clamped r == 0: the reference returns the do_nothing pair here

@@ -76,7 +76,8 @@ def _ungroup(cls, y, num_frames):
 def motionformer_merge(metric, x, _tome_info, num_frames):
     r = _tome_info["r"].pop(0)
     if r > 0:
-        x = _ungroup(x[:, 0:1, :], C.reduce_merge(metric, _regroup(x, num_frames).contiguous(), _tome_info, r), num_frames)
+        # 'b (s f) d -> (b f) s d', merge, back, cls in front: by the kernel's addressing, no copies
+        x = C.reduce_merge_regrouped(metric, x, _tome_info, r, num_frames)
     return x
 
 
@@ -90,7 +91,7 @@ def motionformer_drop(metric, x, _tome_info, num_frames):
 def motionformer_hybrid(metric, x, _tome_info, num_frames):
     r = _tome_info["r"].pop(0)
     if r > 0:
-        x = _ungroup(x[:, 0:1, :], C.reduce_hybrid(metric, _regroup(x, num_frames).contiguous(), _tome_info, r), num_frames)
+        x = C.reduce_merge_regrouped(metric, x, _tome_info, r, num_frames, hybrid=True)
     return x
 
 

@@ -69,7 +69,9 @@ def _ungroup(cls, y, B, T):
 def timesformer_merge(metric, x, _tome_info, B, T, num_spatial_tokens):
     r = _tome_info["r"].pop(0)
     if r > 0:
-        x = _ungroup(x[:, 0:1, :], C.reduce_merge(metric, _regroup(x, B, T, num_spatial_tokens), _tome_info, r), B, T)
+        # 'b (p t) m -> (b t) p m', merge, '(b t) p m -> b (p t) m', cls back in front: done by the kernel's
+        # addressing (tome_merge_wavg_regrouped), not by permuted copies
+        x = C.reduce_merge_regrouped(metric, x, _tome_info, r, T)
     return x
 
 
@@ -83,7 +85,7 @@ def timesformer_drop(metric, x, _tome_info, B, T, num_spatial_tokens):
 def timesformer_hybrid(metric, x, _tome_info, B, T, num_spatial_tokens):
     r = _tome_info["r"].pop(0)
     if r > 0:
-        x = _ungroup(x[:, 0:1, :], C.reduce_hybrid(metric, _regroup(x, B, T, num_spatial_tokens), _tome_info, r), B, T)
+        x = C.reduce_merge_regrouped(metric, x, _tome_info, r, T, hybrid=True)
     return x
 
 
