@@ -541,6 +541,12 @@ template <typename TX> __device__ __forceinline__ TX *group_ptr(TX *p, const Tok
 
 // One destination row (odd token 2j+1 plus every source merged into it), whole wave, contract order:
 // own term first, then the sources in src_idx (rank) order found by ballot-scanning dst_idx.
+// Two shapes of the same arithmetic:
+//   * rows of at most 2*64 lane-chunks (C <= 1024 bf16 / 512 fp32 with 16-byte lanes): the sources of one
+//     64-rank block are compacted onto lanes 0..nsrc-1 (ds_permute), their tokens and sizes fetched as ONE
+//     vector load each, and their row chunks fetched four sources at a time before the sequential adds --
+//     a destination with k sources costs ~2 + k/4 dependent memory round trips instead of ~2k;
+//   * anything wider: the plain sequential loop.
 template <typename TX, typename TS, int VEC, int OP>
 __device__ __forceinline__ void merge_dst_row(const TX *__restrict__ xg, const TS *__restrict__ sg, int C,
                                               int64_t tstride, int r, int g, int j,
@@ -551,10 +557,114 @@ __device__ __forceinline__ void merge_dst_row(const TX *__restrict__ xg, const T
     const TX *xr = xg + (int64_t)t * tstride;
     float s_own = 1.0f;
     if (OP == OP_WAVG) s_own = sg ? to_f32(sg[t]) : 1.0f;
+    const bool narrow_row = C <= 2 * WAVE * VEC;
+    constexpr int NB = VEC >= 8 ? 2 : 4;  // source rows fetched together (register budget)
 
-    // edges into this destination, first 64 ranks (covers every r <= 64 in one ballot)
+    if (narrow_row) {
+        const int c0 = lane * VEC, c1 = (WAVE + lane) * VEC;
+        const bool a0 = c0 < C, a1 = c1 < C;
+        float acc0[VEC], acc1[VEC];
+        if (a0) load_pack<TX, VEC>(xr + c0, acc0);
+        if (a1) load_pack<TX, VEC>(xr + c1, acc1);
+        // hybrid: does any incoming edge fall below the threshold (merge.py:326)?
+        bool kill = false;
+        if (keep && OP != OP_DROP) {
+            for (int base = 0; base < r; base += WAVE) {
+                const int k = base + lane;
+                const bool m = (k < r) && ((int)dstg[k] == j);
+                kill = kill || (__ballot(m && keep[(int64_t)g * r + k] == 0) != 0ull);
+            }
+        }
+        float ssum = s_own;
+        int cnt = 1;
+        if (OP == OP_WAVG) {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                if (a0) acc0[e] = __fmul_rn(acc0[e], s_own);
+                if (a1) acc1[e] = __fmul_rn(acc1[e], s_own);
+            }
+        }
+        if (kill) {
+            if (OP == OP_WAVG) ssum = __fmul_rn(ssum, 0.0f);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                if (a0) acc0[e] = __fmul_rn(acc0[e], 0.0f);
+                if (a1) acc1[e] = __fmul_rn(acc1[e], 0.0f);
+            }
+        }
+        if (OP != OP_DROP) {
+            for (int base = 0; base < r; base += WAVE) {
+                const int k = base + lane;
+                const bool m = (k < r) && ((int)dstg[k] == j);
+                const unsigned long long mk = __ballot(m);
+                if (mk == 0ull) continue;
+                const int nsrc = __popcll(mk);
+                // lane L < nsrc learns the lane (= rank offset) of the L-th source of this block
+                const int myrank = __popcll(mk & ((1ull << lane) - 1ull));
+                const int kL = __builtin_amdgcn_ds_permute(m ? myrank * 4 : 63 * 4 + 256, m ? lane : 0);
+                int tsL = 0;
+                float sL = 1.0f;
+                if (lane < nsrc) {
+                    tsL = 2 * (int)srcg[base + kL];
+                    if (OP == OP_WAVG && sg) sL = to_f32(sg[tsL]);
+                }
+                for (int e0 = 0; e0 < nsrc; e0 += NB) {
+                    typedef Pack<TX, VEC> __attribute__((aligned(sizeof(TX) * VEC))) PK;
+                    PK p0[NB], p1[NB];  // raw chunks of up to NB source rows, all in flight together
+                    float sq[NB];
+#pragma unroll
+                    for (int u = 0; u < NB; ++u) {
+                        const int e = (e0 + u < nsrc) ? e0 + u : nsrc - 1;
+                        const int tsu = __builtin_amdgcn_readlane(tsL, e);
+                        sq[u] = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(sL), e));
+                        const TX *sr = xg + (int64_t)tsu * tstride;
+                        if (a0) p0[u] = *reinterpret_cast<const PK *>(sr + c0);
+                        if (a1) p1[u] = *reinterpret_cast<const PK *>(sr + c1);
+                    }
+#pragma unroll
+                    for (int u = 0; u < NB; ++u) {
+                        if (e0 + u < nsrc) {
+#pragma unroll
+                            for (int e = 0; e < VEC; ++e) {
+                                if (a0) {
+                                    const float v = to_f32(p0[u].e[e]);
+                                    acc0[e] = reduce_step<OP>(acc0[e], (OP == OP_WAVG) ? __fmul_rn(v, sq[u]) : v);
+                                }
+                                if (a1) {
+                                    const float v = to_f32(p1[u].e[e]);
+                                    acc1[e] = reduce_step<OP>(acc1[e], (OP == OP_WAVG) ? __fmul_rn(v, sq[u]) : v);
+                                }
+                            }
+                            if (OP == OP_WAVG) ssum = __fadd_rn(ssum, sq[u]);
+                            ++cnt;
+                        }
+                    }
+                }
+            }
+        }
+        if (OP == OP_WAVG) {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                if (a0) acc0[e] = __fdiv_rn(acc0[e], ssum);
+                if (a1) acc1[e] = __fdiv_rn(acc1[e], ssum);
+            }
+        } else if (OP == TOME_MEAN && cnt > 1) {
+            const float fc = (float)cnt;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                if (a0) acc0[e] = __fdiv_rn(acc0[e], fc);
+                if (a1) acc1[e] = __fdiv_rn(acc1[e], fc);
+            }
+        }
+        if (a0) store_pack<TX, VEC>(orow + c0, acc0);
+        if (a1) store_pack<TX, VEC>(orow + c1, acc1);
+        if (OP == OP_WAVG && lane == 0) *srow = from_f32<TS>(ssum);
+        return;
+    }
+
+    // wide rows: sequential form
     unsigned long long mask0 = 0ull;
-    bool kill = false;  // hybrid: some incoming edge is below the threshold (merge.py:326)
+    bool kill = false;
     if (OP != OP_DROP) {
         for (int base = 0; base < r; base += WAVE) {
             const int k = base + lane;
@@ -564,7 +674,6 @@ __device__ __forceinline__ void merge_dst_row(const TX *__restrict__ xg, const T
             if (keep) kill = kill || (__ballot(m && keep[(int64_t)g * r + k] == 0) != 0ull);
         }
     }
-
     float ssum = s_own;
     int cnt = 1;
     if (OP == OP_WAVG) {
@@ -716,14 +825,39 @@ __global__ __launch_bounds__(256) void k_merge_rows_fast(const TX *__restrict__ 
     const int To = T_ - r;
     const int rg_per_group = (To + R - 1) / R;
     const int64_t w = (int64_t)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if (w >= (int64_t)n * rg_per_group) {
+    const int64_t n_main = (int64_t)n * rg_per_group;
+    const int64_t n_edge = (OP == OP_DROP) ? 0 : (int64_t)n * r;
+    if (w >= n_main + n_edge) {
         // the class tokens kept aside by the regrouped callers (timesformer.py:89,107): plain row copies
-        const int64_t b = w - (int64_t)n * rg_per_group;
+        const int64_t b = w - n_main - n_edge;
         if (b < cls_rows) {
             const uint4 *src = reinterpret_cast<const uint4 *>(x + b * lin.outer_stride);
             uint4 *dst = reinterpret_cast<uint4 *>(xout + b * lout.outer_stride);
             for (int c = lane; c < cpr; c += WAVE) dst[c] = src[c];
         }
+        return;
+    }
+    if (w >= n_main) {
+        // edge waves: one per (group, rank k).  The wave of the FIRST edge into a destination builds that
+        // row (all its sources, rank order); the others leave.  Destinations with sources therefore never
+        // hold up the streaming waves above, and run concurrently with them.
+        const int64_t ew = w - n_main;
+        const int g = (int)(ew / r);
+        const int k = (int)(ew - (int64_t)g * r);
+        const int64_t *dstg = dst_idx + (int64_t)g * r;
+        const int j = (int)dstg[k];
+        bool earlier = false;
+        for (int base = 0; base < k; base += WAVE) {
+            const int kk = base + lane;
+            earlier = earlier || (__ballot((kk < k) && ((int)dstg[kk] == j)) != 0ull);
+        }
+        if (earlier) return;
+        const int T1e = (T_ + 1) >> 1, Ue = T1e - r;
+        const int o = out_row_dst(j, Ue, distill);
+        merge_dst_row<TX, TS, VEC, OP>(group_ptr(x, lin, g), size ? size + (int64_t)g * T_ : nullptr, C, lin.tok_stride,
+                                       r, g, j, src_idx + (int64_t)g * r, dstg, keep,
+                                       group_ptr(xout, lout, g) + (int64_t)o * lout.tok_stride,
+                                       sout ? sout + (int64_t)g * To + o : nullptr, lane);
         return;
     }
     const int g = (int)(w / rg_per_group);
@@ -823,23 +957,6 @@ __global__ __launch_bounds__(256) void k_merge_rows_fast(const TX *__restrict__ 
         const bool mine_has_edges = lane == 0 ? e0 : (lane == 1 ? e1 : (lane == 2 ? e2 : e3));
         if (!mine_has_edges) sout[(int64_t)g * To + o0 + lane] = from_f32<TS>(my_s);
     }
-    // rows that receive sources: sequential weighted sum in the contract's order
-    if ((vmask & 1ull) && e0)
-        merge_dst_row<TX, TS, VEC, OP>(xg, sg, C, lin.tok_stride, r, g, j0, srcg, dstg, keep,
-                                       og + (int64_t)(o0) * lout.tok_stride,
-                                       sout ? sout + (int64_t)g * To + o0 : nullptr, lane);
-    if ((vmask & 2ull) && e1)
-        merge_dst_row<TX, TS, VEC, OP>(xg, sg, C, lin.tok_stride, r, g, j1, srcg, dstg, keep,
-                                       og + (int64_t)(o0 + 1) * lout.tok_stride,
-                                       sout ? sout + (int64_t)g * To + o0 + 1 : nullptr, lane);
-    if ((vmask & 4ull) && e2)
-        merge_dst_row<TX, TS, VEC, OP>(xg, sg, C, lin.tok_stride, r, g, j2, srcg, dstg, keep,
-                                       og + (int64_t)(o0 + 2) * lout.tok_stride,
-                                       sout ? sout + (int64_t)g * To + o0 + 2 : nullptr, lane);
-    if ((vmask & 8ull) && e3)
-        merge_dst_row<TX, TS, VEC, OP>(xg, sg, C, lin.tok_stride, r, g, j3, srcg, dstg, keep,
-                                       og + (int64_t)(o0 + 3) * lout.tok_stride,
-                                       sout ? sout + (int64_t)g * To + o0 + 3 : nullptr, lane);
 }
 
 // k_unmerge_rows: merge.py:87-100 as a scatter from the merged sequence: one wave per INPUT row; a
@@ -1172,7 +1289,7 @@ static int launch_merge_rows(const void *x, const void *size, int64_t n, int64_t
     if (vec_ok && cpr <= FAST_NIT * WAVE) {
         int R = (int)((FAST_NIT * WAVE) / cpr);
         if (R > FAST_MAXR) R = FAST_MAXR;
-        const int64_t waves = n * ((To + R - 1) / R) + cls_rows;
+        const int64_t waves = n * ((To + R - 1) / R) + (OP == OP_DROP ? 0 : n * r) + cls_rows;
         hipLaunchKernelGGL((k_merge_rows_fast<TX, TS, OP>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st,
                            (const TX *)x, (const TS *)size, (int)n, (int)T, (int)C, (int)r, R, (int)cpr, src, dst, unm,
                            distill, keep, (TX *)xout, (TS *)sout, lin, lout, cls_rows);
