@@ -811,7 +811,7 @@ __global__ __launch_bounds__(256) void k_merge_rows(const TX *__restrict__ x, co
 #define FAST_NIT 6
 #define FAST_MAXR 4
 
-template <typename TX, typename TS, int OP>
+template <typename TX, typename TS, int OP, int NIT>
 __global__ __launch_bounds__(256) void k_merge_rows_fast(const TX *__restrict__ x, const TS *__restrict__ size,
                                                          int n, int T_, int C, int r, int R, int cpr,
                                                          const int64_t *__restrict__ src_idx,
@@ -866,7 +866,6 @@ __global__ __launch_bounds__(256) void k_merge_rows_fast(const TX *__restrict__ 
     const TX *xg = group_ptr(x, lin, g);
     TX *og = group_ptr(xout, lout, g);
     const TS *sg = size ? size + (int64_t)g * T_ : nullptr;
-    const int64_t *srcg = src_idx ? src_idx + (int64_t)g * r : nullptr;
     const int64_t *dstg = dst_idx ? dst_idx + (int64_t)g * r : nullptr;
 
     // per-row facts, computed by lanes 0..R-1 in parallel (one index load, then one size load) and
@@ -915,10 +914,10 @@ __global__ __launch_bounds__(256) void k_merge_rows_fast(const TX *__restrict__ 
 
     // flattened chunk loop: chunk q of the R-row slab -> (row q / cpr, 16-byte column q % cpr)
     const int total = R * cpr;
-    uint4 raw[FAST_NIT];
-    int rowof[FAST_NIT];
+    uint4 raw[NIT];
+    int rowof[NIT];
 #pragma unroll
-    for (int it = 0; it < FAST_NIT; ++it) {
+    for (int it = 0; it < NIT; ++it) {
         const int q = it * WAVE + lane;
         const int rr = (q >= cpr) + (q >= 2 * cpr) + (q >= 3 * cpr);
         const int cc = q - rr * cpr;
@@ -933,7 +932,7 @@ __global__ __launch_bounds__(256) void k_merge_rows_fast(const TX *__restrict__ 
     // format (the fp32 product cannot overflow): those rows move as raw bits
     constexpr bool narrow = sizeof(TX) == 2;
 #pragma unroll
-    for (int it = 0; it < FAST_NIT; ++it) {
+    for (int it = 0; it < NIT; ++it) {
         const int rr = rowof[it];
         if (rr < 0) continue;
         const int q = it * WAVE + lane;
@@ -1287,12 +1286,26 @@ static int launch_merge_rows(const void *x, const void *size, int64_t n, int64_t
     const bool vec_ok = (C % VEC == 0) && aligned16(x) && aligned16(xout);
     const int64_t cpr = C / VEC;  // 16-byte chunks per row
     if (vec_ok && cpr <= FAST_NIT * WAVE) {
-        int R = (int)((FAST_NIT * WAVE) / cpr);
+        // rows per wave: measured on MI355X, a plain 16-byte copy runs fastest with ONE load per lane in
+        // flight and many waves (6.0-6.9 TB/s) and loses ~10 % at four; NIT=3 (two 1536-byte rows per wave)
+        // is the smallest slab that still keeps every lane busy for 768-channel bf16 tokens
+        static const int nit_pref = [] {
+            const char *e = getenv("TOME_MERGE_NIT");
+            int v = e ? atoi(e) : 0;
+            return (v == 3 || v == 6) ? v : 6;
+        }();
+        const int nit = (cpr <= 3 * WAVE) ? nit_pref : FAST_NIT;
+        int R = (int)((nit * WAVE) / cpr);
         if (R > FAST_MAXR) R = FAST_MAXR;
         const int64_t waves = n * ((To + R - 1) / R) + (OP == OP_DROP ? 0 : n * r) + cls_rows;
-        hipLaunchKernelGGL((k_merge_rows_fast<TX, TS, OP>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st,
-                           (const TX *)x, (const TS *)size, (int)n, (int)T, (int)C, (int)r, R, (int)cpr, src, dst, unm,
-                           distill, keep, (TX *)xout, (TS *)sout, lin, lout, cls_rows);
+        if (nit == 3)
+            hipLaunchKernelGGL((k_merge_rows_fast<TX, TS, OP, 3>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st,
+                               (const TX *)x, (const TS *)size, (int)n, (int)T, (int)C, (int)r, R, (int)cpr, src, dst,
+                               unm, distill, keep, (TX *)xout, (TS *)sout, lin, lout, cls_rows);
+        else
+            hipLaunchKernelGGL((k_merge_rows_fast<TX, TS, OP, 6>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st,
+                               (const TX *)x, (const TS *)size, (int)n, (int)T, (int)C, (int)r, R, (int)cpr, src, dst,
+                               unm, distill, keep, (TX *)xout, (TS *)sout, lin, lout, cls_rows);
         return check_launch("k_merge_rows_fast");
     }
     if (cls_rows) return fail(TOME_EINVAL, "regrouped merge needs rows of whole 16-byte chunks (C=%lld)", (long long)C);
