@@ -321,3 +321,45 @@ def test_merge_wavg_regrouped_equals_rearranged(B, F, P, C, r, dtype):
         assert torch.equal(got_full, want_full)
         assert torch.equal(got_s, want_s)
         x_full, size, Pc = got_full, got_s, P2
+
+
+@pytest.mark.parametrize("cls", [False, True])
+@pytest.mark.parametrize("where", ["a_row", "b_row", "both", "b_first_and_later", "inf_value"])
+def test_nan_semantics_zero_tokens(where, cls):
+    """A zero token has a NaN unit vector (merge.py:51 divides by the norm without epsilon): every score it
+    takes part in is NaN, torch.max returns NaN with the FIRST NaN column, argsort puts NaN rows first.
+    The kernels ignore NaN in the MFMA pass and restore these semantics from per-token flags; the oracle
+    implements torch's rule directly."""
+    from tome import _abi
+    n, T, D = 3, 70, 64
+    metric = synth.normal_like((n, T, D), 2718).copy()
+    if where in ("a_row", "both"):
+        metric[0, 2 * 7] = 0.0          # A row 7 of group 0
+        metric[2, 2 * 30] = 0.0
+    if where in ("b_row", "both"):
+        metric[1, 2 * 5 + 1] = 0.0      # B row 5 of group 1
+    if where == "b_first_and_later":
+        metric[0, 2 * 20 + 1] = 0.0
+        metric[0, 2 * 3 + 1] = 0.0      # first bad column is 3
+    if where == "inf_value":
+        metric[1, 2 * 9, 5] = np.inf    # inf / inf = NaN in one channel
+    for r in (4, 35):
+        plan = oracle.match(metric, r, cls, False)
+        got = _abi.match(dev(metric), r, cls, False, want_node_max=True)
+        np.testing.assert_array_equal(got.src_idx.cpu().numpy(), plan.src_idx)
+        np.testing.assert_array_equal(got.dst_idx.cpu().numpy(), plan.dst_idx)
+        np.testing.assert_array_equal(got.unm_idx.cpu().numpy(), plan.unm_idx)
+        gm, om = got.node_max.cpu().numpy(), plan.node_max
+        np.testing.assert_array_equal(np.isnan(gm), np.isnan(om))
+        np.testing.assert_array_equal(gm[~np.isnan(gm)], om[~np.isnan(om)])
+    # and torch agrees with the oracle on which rows are NaN / where they point (reference semantics)
+    m = torch.from_numpy(metric)
+    u = m / m.norm(dim=-1, keepdim=True)
+    s = u[:, ::2] @ u[:, 1::2].transpose(-1, -2)
+    if cls:
+        s[:, 0, :] = -float("inf")
+    tv, ti = s.max(-1)
+    plan = oracle.match(metric, 4, cls, False)
+    np.testing.assert_array_equal(torch.isnan(tv).numpy(), np.isnan(plan.node_max))
+    nanrows = np.isnan(plan.node_max)
+    np.testing.assert_array_equal(ti.numpy()[nanrows], plan.node_idx[nanrows])

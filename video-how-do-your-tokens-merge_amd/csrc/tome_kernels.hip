@@ -112,7 +112,8 @@ template <typename T, int NCH>
 __global__ __launch_bounds__(256) void k_unit_rows(const T *__restrict__ metric, int64_t stride_n,
                                                    int64_t stride_t, int n, int T_, int D,
                                                    float *__restrict__ unitA, float *__restrict__ unitB,
-                                                   int64_t groupA_f4, int64_t groupB_f4) {
+                                                   int64_t groupA_f4, int64_t groupB_f4,
+                                                   uint8_t *__restrict__ badA, uint8_t *__restrict__ badB) {
     const int lane = threadIdx.x & 63;
     const int b8 = lane & 7;
     const int64_t tok = ((int64_t)blockIdx.x * (blockDim.x >> 3)) + (threadIdx.x >> 3);
@@ -150,10 +151,10 @@ __global__ __launch_bounds__(256) void k_unit_rows(const T *__restrict__ metric,
         }
     }
     const float nr = __builtin_sqrtf(ss);
-    if (!live) return;
     const int rowi = t >> 1;
     f32x4 *dst = reinterpret_cast<f32x4 *>((t & 1) ? unitB : unitA) + (int64_t)g * ((t & 1) ? groupB_f4 : groupA_f4);
     const int tile = rowi >> 5, slot = rowi & 31;
+    bool nan_here = false;  // a zero / inf / NaN token has NaN unit channels (merge.py:51 has no epsilon)
 #pragma unroll
     for (int it = 0; it < NCH; ++it) {
         const int b = b8 + 8 * it;
@@ -163,14 +164,25 @@ __global__ __launch_bounds__(256) void k_unit_rows(const T *__restrict__ metric,
             ev.y = __fdiv_rn(v[it][2], nr); od.y = __fdiv_rn(v[it][3], nr);
             ev.z = __fdiv_rn(v[it][4], nr); od.z = __fdiv_rn(v[it][5], nr);
             ev.w = __fdiv_rn(v[it][6], nr); od.w = __fdiv_rn(v[it][7], nr);
+            nan_here = nan_here || (ev.x != ev.x) || (ev.y != ev.y) || (ev.z != ev.z) || (ev.w != ev.w) ||
+                       (od.x != od.x) || (od.y != od.y) || (od.z != od.z) || (od.w != od.w);
         } else {
             ev.x = ev.y = ev.z = ev.w = 0.0f;
             od = ev;
         }
         // block b -> pairs s = 4b..4b+3 -> chunk c = b/8 = it, q = b%8 = b8
-        const int64_t f = frag_index(tile, NCH, it, b8, slot);
-        dst[f] = ev;
-        dst[f + 32] = od;
+        if (live) {
+            const int64_t f = frag_index(tile, NCH, it, b8, slot);
+            dst[f] = ev;
+            dst[f + 32] = od;
+        }
+    }
+    // one flag per token: does its unit vector hold a NaN (then every score it takes part in is NaN)
+    const unsigned long long nan_mask = __ballot(nan_here);
+    if (live && b8 == 0) {
+        const uint8_t flag = ((nan_mask >> (lane & ~7)) & 0xFFull) ? 1 : 0;
+        if (t & 1) badB[(int64_t)g * (T_ >> 1) + rowi] = flag;
+        else badA[(int64_t)g * ((T_ + 1) >> 1) + rowi] = flag;
     }
 }
 
@@ -179,7 +191,8 @@ template <typename T>
 __global__ __launch_bounds__(256) void k_unit_rows_generic(const T *__restrict__ metric, int64_t stride_n,
                                                            int64_t stride_t, int n, int T_, int D, int Dp,
                                                            float *__restrict__ unitA, float *__restrict__ unitB,
-                                                           int64_t groupA_f4, int64_t groupB_f4) {
+                                                           int64_t groupA_f4, int64_t groupB_f4,
+                                                           uint8_t *__restrict__ badA, uint8_t *__restrict__ badB) {
     const int64_t tok = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (tok >= (int64_t)n * T_) return;
     const int g = (int)(tok / T_);
@@ -197,12 +210,16 @@ __global__ __launch_bounds__(256) void k_unit_rows_generic(const T *__restrict__
     const float nr = __builtin_sqrtf(ss);
     const int rowi = t >> 1, tile = rowi >> 5, slot = rowi & 31, nchunk = Dp >> 6;
     float *dst = ((t & 1) ? unitB : unitA) + 4 * (int64_t)g * ((t & 1) ? groupB_f4 : groupA_f4);
+    bool nan_here = false;
     for (int k = 0; k < Dp; ++k) {
         const float u = (k < D) ? __fdiv_rn(to_f32(row[k]), nr) : 0.0f;
+        nan_here = nan_here || (u != u);
         const int s = k >> 1, h = k & 1;
         const int64_t f = frag_index(tile, nchunk, s >> 5, (s & 31) >> 2, slot + 32 * h);
         dst[4 * f + (s & 3)] = u;
     }
+    if (t & 1) badB[(int64_t)g * (T_ >> 1) + rowi] = nan_here ? 1 : 0;
+    else badA[(int64_t)g * ((T_ + 1) >> 1) + rowi] = nan_here ? 1 : 0;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -399,7 +416,9 @@ __device__ __forceinline__ int out_row_dst(int j, int U, int distill) {
 
 __global__ __launch_bounds__(256) void k_rank_select(const float *__restrict__ part_max,
                                                      const int *__restrict__ part_idx, int nparts, int n, int T1,
-                                                     int r, int class_token, int distill_token,
+                                                     int T2, const uint8_t *__restrict__ badA,
+                                                     const uint8_t *__restrict__ badB, int r, int class_token,
+                                                     int distill_token,
                                                      int64_t *__restrict__ src_idx,
                                                      int64_t *__restrict__ dst_idx,
                                                      int64_t *__restrict__ unm_idx, float *__restrict__ node_max,
@@ -411,6 +430,21 @@ __global__ __launch_bounds__(256) void k_rank_select(const float *__restrict__ p
     const float *pm = part_max + (int64_t)g * nparts * T1;
     const int *pi = part_idx + (int64_t)g * nparts * T1;
     const int i = blockIdx.x * 64 + (threadIdx.x >> 2);
+    // NaN semantics of torch.max (merge.py:64): a NaN score wins and the FIRST NaN column keeps the row.
+    // NaN scores come only from tokens whose unit vector is NaN (flags from k_unit_rows); the MFMA pass
+    // ignored them (x > NaN is false), so they are put back here.
+    __shared__ int s_first_bad;
+    const int jmin = distill_token ? 1 : 0;  // merge.py:61-62: column 0 is -inf when protected
+    if (threadIdx.x == 0) s_first_bad = 0x7fffffff;
+    __syncthreads();
+    if (badB) {
+        int fb = 0x7fffffff;
+        for (int j = jmin + (int)threadIdx.x; j < T2; j += blockDim.x)
+            if (badB[(int64_t)g * T2 + j]) { fb = j; break; }
+        if (fb != 0x7fffffff) atomicMin(&s_first_bad, fb);
+    }
+    __syncthreads();
+    const int first_bad = s_first_bad;
     for (int j = threadIdx.x; j < T1p; j += blockDim.x) {
         unsigned long long key = 0ull;
         if (j < T1) {
@@ -421,6 +455,7 @@ __global__ __launch_bounds__(256) void k_rank_select(const float *__restrict__ p
             float best = pv[0];
 #pragma unroll
             for (int p = 1; p < MAX_WJ; ++p) best = pv[p] > best ? pv[p] : best;
+            if (badA && (badA[(int64_t)g * T1 + j] ? jmin < T2 : first_bad != 0x7fffffff)) best = __builtin_nanf("");
             if (class_token && j == 0) best = -INFINITY;  // merge.py:59-60: the class token's row is -inf
             key = ((unsigned long long)sort_key(best) << 32) | (0xFFFFFFFFu - (uint32_t)j);
         }
@@ -454,6 +489,17 @@ __global__ __launch_bounds__(256) void k_rank_select(const float *__restrict__ p
         const bool up = pv[p] > best;
         best = up ? pv[p] : best;
         bidx = up ? pj[p] : bidx;
+    }
+    if (badA) {
+        if (badA[(int64_t)g * T1 + i]) {
+            if (jmin < T2) {
+                best = __builtin_nanf("");
+                bidx = jmin;
+            }
+        } else if (first_bad != 0x7fffffff) {
+            best = __builtin_nanf("");
+            bidx = first_bad;
+        }
     }
     if (class_token && i == 0) {
         best = -INFINITY;
@@ -1086,6 +1132,7 @@ extern "C" int tome_profile_read(float *stage_ms, int max_stages) {
 struct MatchWs {
     float *unitA, *unitB, *part_max;
     int *part_idx, *rank;
+    uint8_t *badA, *badB;
     int ntA, ntB, nchunk;
     int64_t groupA_f4, groupB_f4;  // float4 per group of each unit set
     size_t bytes;
@@ -1106,6 +1153,8 @@ static MatchWs carve(void *base, int64_t n, int64_t T, int64_t D) {
     w.part_max = (float *)(b + off); off = align_up(off + sizeof(float) * (size_t)(n * MAX_WJ * T1), 256);
     w.part_idx = (int *)(b + off); off = align_up(off + sizeof(int) * (size_t)(n * MAX_WJ * T1), 256);
     w.rank = (int *)(b + off); off = align_up(off + sizeof(int) * (size_t)(n * T1), 256);
+    w.badA = (uint8_t *)(b + off); off = align_up(off + (size_t)(n * T1), 256);
+    w.badB = (uint8_t *)(b + off); off = align_up(off + (size_t)(n * (T2 > 0 ? T2 : 1)), 256);
     w.bytes = off;
     return w;
 }
@@ -1115,15 +1164,16 @@ extern "C" size_t tome_match_workspace_bytes(int64_t n, int64_t T, int64_t D) {
     return carve(nullptr, n, T, D).bytes;
 }
 
-static int launch_select(const MatchWs &w, int nparts, int64_t n, int64_t T, int64_t re, int class_token,
+static int launch_select(const MatchWs &w, int nparts, bool nan_flags, int64_t n, int64_t T, int64_t re, int class_token,
                          int distill_token, int64_t *src_idx, int64_t *dst_idx, int64_t *unm_idx,
                          float *node_max, int32_t *row_map, hipStream_t st) {
     const int T1 = (int)((T + 1) / 2);
     dim3 grid((T1 + 63) / 64, (unsigned)n);
     const int quarter = (((T1 + 3) >> 2) + 1) & ~1;
     const size_t lds = sizeof(unsigned long long) * (size_t)(4 * quarter);
-    hipLaunchKernelGGL(k_rank_select, grid, dim3(256), lds, st, w.part_max, w.part_idx, nparts, (int)n, T1, (int)re,
-                       class_token, distill_token, src_idx, dst_idx, unm_idx, node_max, w.rank, row_map);
+    hipLaunchKernelGGL(k_rank_select, grid, dim3(256), lds, st, w.part_max, w.part_idx, nparts, (int)n, T1,
+                       (int)(T / 2), nan_flags ? w.badA : nullptr, nan_flags ? w.badB : nullptr, (int)re, class_token,
+                       distill_token, src_idx, dst_idx, unm_idx, node_max, w.rank, row_map);
     if (int rc = check_launch("k_rank_select")) return rc;
     if (class_token) {
         hipLaunchKernelGGL(k_compact_unm, dim3((unsigned)n), dim3(256), 0, st, w.rank, T1, (int)re,
@@ -1164,7 +1214,7 @@ extern "C" int tome_match(const void *metric, int dtype, int64_t n, int64_t T, i
 #define UNIT_FAST(TY, NCH)                                                                                    \
     hipLaunchKernelGGL((k_unit_rows<TY, NCH>), dim3((unsigned)((n * T + 31) / 32)), dim3(256), 0, st,          \
                        (const TY *)metric, stride_n, stride_t, (int)n, (int)T, (int)D, w.unitA, w.unitB,       \
-                       w.groupA_f4, w.groupB_f4);                                                              \
+                       w.groupA_f4, w.groupB_f4, w.badA, w.badB);                                              \
     launched = true
 #define UNIT_NCH(TY)                                       \
     switch (w.nchunk) {                                    \
@@ -1181,7 +1231,7 @@ extern "C" int tome_match(const void *metric, int dtype, int64_t n, int64_t T, i
 #define UNIT_GENERIC(TY)                                                                                       \
     hipLaunchKernelGGL((k_unit_rows_generic<TY>), dim3((unsigned)((n * T + 255) / 256)), dim3(256), 0, st,      \
                        (const TY *)metric, stride_n, stride_t, (int)n, (int)T, (int)D, w.nchunk * 64, w.unitA,  \
-                       w.unitB, w.groupA_f4, w.groupB_f4)
+                       w.unitB, w.groupA_f4, w.groupB_f4, w.badA, w.badB)
     switch (dtype) {
     case TOME_F32:
         if (fast) { UNIT_NCH(float) }
@@ -1231,7 +1281,7 @@ extern "C" int tome_match(const void *metric, int dtype, int64_t n, int64_t T, i
     // 3. rank + select
     int rc = TOME_OK;
     for (int rep = 0; rep < prof_reps && rc == TOME_OK; ++rep)
-        rc = launch_select(w, WJ, n, T, re, class_token, distill_token, src_idx, dst_idx, unm_idx, node_max, row_map, st);
+        rc = launch_select(w, WJ, true, n, T, re, class_token, distill_token, src_idx, dst_idx, unm_idx, node_max, row_map, st);
     prof_mark(3, st);
     g_prof.valid = g_prof.on && rc == TOME_OK;
     return rc;
@@ -1256,7 +1306,7 @@ extern "C" int tome_match_scores(const float *scores, int64_t n, int64_t T, int6
     hipLaunchKernelGGL(k_rowmax_given, dim3(nb), dim3(256), 0, st, scores, (int)n, T1, T2, class_token,
                        distill_token, w.part_max, w.part_idx);
     if (int rc = check_launch("k_rowmax_given")) return rc;
-    return launch_select(w, 1, n, T, re, class_token, distill_token, src_idx, dst_idx, unm_idx, node_max, row_map,
+    return launch_select(w, 1, false, n, T, re, class_token, distill_token, src_idx, dst_idx, unm_idx, node_max, row_map,
                          st);
 }
 
