@@ -75,6 +75,21 @@ int tome_match(const void *metric, int dtype, int64_t n, int64_t T, int64_t D, i
                void *workspace, size_t workspace_bytes, tome_stream_t stream);
 
 /*
+ * tome_match_keys  <-  the metric producer fused in front of tome_match:
+ *     metric = k.mean(1)   (tome/patch/videomae.py:72-73, timesformer.py:83, motionformer.py:143-144,
+ *     vivit.py:123-124), then bipartite_soft_matching(metric, ...) (merge.py:49-73).
+ *
+ * keys: per-head attention keys [n,H,T,D] of `dtype`, element strides (stride_n, stride_h, stride_t, 1) --
+ *       e.g. the k slice of the qkv projection buffer, no copy; every stride and the base must be 16-byte
+ *       aligned; D must be 64.  The head mean is taken as torch does on CPU: fp32 sum in head order, one
+ *       division by H, one rounding to `dtype`; everything after is tome_match.
+ */
+int tome_match_keys(const void *keys, int dtype, int64_t n, int64_t H, int64_t T, int64_t D, int64_t stride_n,
+                    int64_t stride_h, int64_t stride_t, int64_t r, int class_token, int distill_token,
+                    int64_t *src_idx, int64_t *dst_idx, int64_t *unm_idx, float *node_max, int32_t *row_map,
+                    void *workspace, size_t workspace_bytes, tome_stream_t stream);
+
+/*
  * tome_match_scores  <-  the same selection from caller-made scores [n,T1,T2] fp32
  *                        (merge.py:54-57 random_merge / :239-242 random_drop, scores = torch.rand).
  */

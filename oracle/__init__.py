@@ -50,6 +50,8 @@ def lib() -> ctypes.CDLL:
         i64, i32, vp = ctypes.c_int64, ctypes.c_int, ctypes.c_void_p
         L.oracle_effective_r.restype = i64
         L.oracle_effective_r.argtypes = [i64, i64, i32, i32]
+        L.oracle_head_mean.restype = None
+        L.oracle_head_mean.argtypes = [vp, i64, i64, i64, i64, vp]
         L.oracle_match.restype = i64
         L.oracle_match.argtypes = [vp, i64, i64, i64, i64, i32, i32, vp, vp, vp, vp, vp]
         L.oracle_match_scores.restype = i64
@@ -84,6 +86,15 @@ def _p(a: Optional[np.ndarray]):
 
 def effective_r(T: int, r: int, class_token: bool = False, distill_token: bool = False) -> int:
     return int(lib().oracle_effective_r(T, r, int(class_token), int(distill_token)))
+
+
+def head_mean(keys) -> np.ndarray:
+    """[n,H,T,D] -> [n,T,D]: fp32 sum over heads in order, divided by H (torch CPU `k.mean(1)`)."""
+    k = _f32(keys)
+    n, H, T, D = k.shape
+    out = np.empty((n, T, D), np.float32)
+    lib().oracle_head_mean(_p(k), n, H, T, D, _p(out))
+    return out
 
 
 class Plan:

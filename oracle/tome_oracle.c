@@ -212,6 +212,19 @@ ORACLE_API int64_t oracle_match_scores(const float *scores, int64_t n, int64_t T
     return re;
 }
 
+/* metric = k.mean(1) of the patches (videomae.py:72-73 ...): keys [n,H,T,D] fp32 -> out [n,T,D];
+ * fp32 sum in head order, one division by H (what torch's CPU mean does).  The caller rounds the result to
+ * the keys' dtype when that is a 16-bit format. */
+ORACLE_API void oracle_head_mean(const float *keys, int64_t n, int64_t H, int64_t T, int64_t D, float *out) {
+    for (int64_t g = 0; g < n; ++g)
+        for (int64_t t = 0; t < T; ++t)
+            for (int64_t k = 0; k < D; ++k) {
+                float acc = 0.0f;
+                for (int64_t h = 0; h < H; ++h) acc = acc + keys[((g * H + h) * T + t) * D + k];
+                out[(g * T + t) * D + k] = acc / (float)H;
+            }
+}
+
 /* Output row of the merged sequence -> position, honouring the distill layout of
  * merge.py:82-83: [unm[0], dst[0], unm[1:], dst[1:]]. */
 static inline int64_t out_row_unm(int64_t k, int distill) { return (distill && k >= 1) ? k + 1 : k; }

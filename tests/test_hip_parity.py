@@ -363,3 +363,38 @@ def test_nan_semantics_zero_tokens(where, cls):
     np.testing.assert_array_equal(torch.isnan(tv).numpy(), np.isnan(plan.node_max))
     nanrows = np.isnan(plan.node_max)
     np.testing.assert_array_equal(ti.numpy()[nanrows], plan.node_idx[nanrows])
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("cls", [False, True])
+def test_match_keys_fused_head_mean(dtype, cls):
+    """tome_match_keys reads the per-head keys in place (a strided view of a qkv buffer, as the patches hand
+    them over) and must equal: head mean by the oracle's rule (fp32 sum in head order / H, one rounding to the
+    keys' dtype -- bit-identical to torch's CPU `k.mean(1)`), then the ordinary matching."""
+    from tome import _abi
+    from tome.merge import HeadMeanKeys
+    tm = _tome()
+    B, H, N, hd = 3, 12, 197, 64
+    qkv = dev(synth.normal_like((B, N, 3, H, hd), 606), dtype)
+    k = qkv.permute(2, 0, 3, 1, 4)[1]  # [B,H,N,hd], strides of the patches' key view
+    assert not k.is_contiguous() and _abi.keys_fusable(k)
+    k_host = host(k)
+    mean = oracle.head_mean(k_host)
+    if dtype != torch.float32:
+        mean = host(torch.from_numpy(mean).to(dtype))
+    assert np.array_equal(mean, host(k.cpu().mean(1)))  # the rule IS torch's CPU mean
+    for r in (16, 200):
+        plan = oracle.match(mean, r, cls, False)
+        got = _abi.match_keys(k, r, cls, False, want_node_max=True)
+        np.testing.assert_array_equal(got.src_idx.cpu().numpy(), plan.src_idx)
+        np.testing.assert_array_equal(got.dst_idx.cpu().numpy(), plan.dst_idx)
+        np.testing.assert_array_equal(got.unm_idx.cpu().numpy(), plan.unm_idx)
+        np.testing.assert_array_equal(got.node_max.cpu().numpy().view(np.uint32), plan.node_max.view(np.uint32))
+        # through the public API, and with the class-token slice TimeSformer takes
+        merge, _ = tm.bipartite_soft_matching(HeadMeanKeys(k), r, cls)
+        np.testing.assert_array_equal(merge.plan.src_idx.cpu().numpy(), plan.src_idx)
+    sl = k[:, :, 1:, :]
+    assert _abi.keys_fusable(sl)
+    plan = oracle.match(mean[:, 1:, :], 16, False, False)
+    got = _abi.match_keys(sl, 16)
+    np.testing.assert_array_equal(got.unm_idx.cpu().numpy(), plan.unm_idx)

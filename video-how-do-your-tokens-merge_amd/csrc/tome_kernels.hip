@@ -186,6 +186,70 @@ __global__ __launch_bounds__(256) void k_unit_rows(const T *__restrict__ metric,
     }
 }
 
+// k_unit_rows_heads: the metric producer fused in (videomae.py:72-73 `metric = k.mean(1)`, timesformer.py:83,
+// vivit.py:123-124): reads the per-head keys [n,H,T,64] straight from the attention's qkv buffer (any strides
+// with unit channel stride), averages the heads exactly as torch does on CPU -- fp32 sum in head order, one
+// division by H, one rounding to the keys' dtype -- and continues as k_unit_rows.  D = 64 only (one chunk).
+template <typename T>
+__global__ __launch_bounds__(256) void k_unit_rows_heads(const T *__restrict__ keys, int64_t stride_n,
+                                                         int64_t stride_h, int64_t stride_t, int n, int H, int T_,
+                                                         float *__restrict__ unitA, float *__restrict__ unitB,
+                                                         int64_t groupA_f4, int64_t groupB_f4,
+                                                         uint8_t *__restrict__ badA, uint8_t *__restrict__ badB) {
+    const int lane = threadIdx.x & 63;
+    const int b8 = lane & 7;
+    const int64_t tok = ((int64_t)blockIdx.x * (blockDim.x >> 3)) + (threadIdx.x >> 3);
+    const int64_t ntok = (int64_t)n * T_;
+    const bool live = tok < ntok;
+    const int64_t tk = live ? tok : ntok - 1;
+    const int g = (int)(tk / T_);
+    const int t = (int)(tk - (int64_t)g * T_);
+    const T *row = keys + (int64_t)g * stride_n + (int64_t)t * stride_t + 8 * b8;
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.0f;
+#pragma unroll 4
+    for (int h = 0; h < H; ++h) {
+        float kv[8];
+        Load8<T>::run(row + (int64_t)h * stride_h, kv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = __fadd_rn(acc[e], kv[e]);
+    }
+    const float fh = (float)H;
+    float v[8];
+    float part = 0.0f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        v[e] = to_f32(from_f32<T>(__fdiv_rn(acc[e], fh)));  // k.mean(1) in the keys' dtype
+        part = __fmaf_rn(v[e], v[e], part);
+    }
+    float ss = 0.0f;
+    const int base = lane & ~7;
+#pragma unroll
+    for (int l = 0; l < 8; ++l) ss = __fadd_rn(ss, __shfl(part, base + l));
+    const float nr = __builtin_sqrtf(ss);
+    const int rowi = t >> 1;
+    f32x4 *dst = reinterpret_cast<f32x4 *>((t & 1) ? unitB : unitA) + (int64_t)g * ((t & 1) ? groupB_f4 : groupA_f4);
+    f32x4 ev, od;
+    ev.x = __fdiv_rn(v[0], nr); od.x = __fdiv_rn(v[1], nr);
+    ev.y = __fdiv_rn(v[2], nr); od.y = __fdiv_rn(v[3], nr);
+    ev.z = __fdiv_rn(v[4], nr); od.z = __fdiv_rn(v[5], nr);
+    ev.w = __fdiv_rn(v[6], nr); od.w = __fdiv_rn(v[7], nr);
+    const bool nan_here = (ev.x != ev.x) || (ev.y != ev.y) || (ev.z != ev.z) || (ev.w != ev.w) || (od.x != od.x) ||
+                          (od.y != od.y) || (od.z != od.z) || (od.w != od.w);
+    if (live) {
+        const int64_t f = frag_index(rowi >> 5, 1, 0, b8, rowi & 31);
+        dst[f] = ev;
+        dst[f + 32] = od;
+    }
+    const unsigned long long nan_mask = __ballot(nan_here);
+    if (live && b8 == 0) {
+        const uint8_t flag = ((nan_mask >> (lane & ~7)) & 0xFFull) ? 1 : 0;
+        if (t & 1) badB[(int64_t)g * (T_ >> 1) + rowi] = flag;
+        else badA[(int64_t)g * ((T_ + 1) >> 1) + rowi] = flag;
+    }
+}
+
 // Any D (also D % 8 != 0, unaligned rows): one thread per token, scalar accesses, same arithmetic order.
 template <typename T>
 __global__ __launch_bounds__(256) void k_unit_rows_generic(const T *__restrict__ metric, int64_t stride_n,
@@ -1183,6 +1247,44 @@ static int launch_select(const MatchWs &w, int nparts, bool nan_flags, int64_t n
     return TOME_OK;
 }
 
+// shared tail of tome_match / tome_match_keys: stages 2 (similarity + row max) and 3 (rank + select)
+static int match_tail(const MatchWs &w, int64_t n, int64_t T, int64_t re, int class_token, int distill_token,
+                      int64_t *src_idx, int64_t *dst_idx, int64_t *unm_idx, float *node_max, int32_t *row_map,
+                      hipStream_t st) {
+    const int T1 = (int)((T + 1) / 2), T2 = (int)(T / 2);
+    const int prof_reps = g_prof.on ? g_prof.reps : 1;
+    // 2. similarity + row max/argmax: one single-wave workgroup per (group, A tile, j-part); the B tiles are
+    // split into WJ parts so that the launch has >= ~6 waves per SIMD (1024 SIMDs) whatever the batch
+    static const long target_waves = [] {
+        const char *e = getenv("TOME_SCORES_WAVES");  // tuning knob, default from measurements on MI355X
+        long v = e ? atol(e) : 0;
+        return v > 0 ? v : 6144L;
+    }();
+    int WJ = (int)((target_waves + n * w.ntA - 1) / (n * w.ntA));
+    if (WJ > MAX_WJ) WJ = MAX_WJ;
+    if (WJ > w.ntB) WJ = w.ntB;
+    if (WJ < 1) WJ = 1;
+    const unsigned nb2 = (unsigned)(((n + 7) / 8) * 8 * w.ntA * WJ);
+    for (int rep = 0; rep < prof_reps; ++rep)
+    if (w.nchunk == 1)
+        hipLaunchKernelGGL(k_scores_rowmax<true>, dim3(nb2), dim3(64), 0, st, (const f32x4 *)w.unitA,
+                           (const f32x4 *)w.unitB, (int)n, T1, T2, w.nchunk, w.ntA, w.ntB, WJ, w.groupA_f4,
+                           w.groupB_f4, distill_token, w.part_max, w.part_idx);
+    else
+        hipLaunchKernelGGL(k_scores_rowmax<false>, dim3(nb2), dim3(64), 0, st, (const f32x4 *)w.unitA,
+                           (const f32x4 *)w.unitB, (int)n, T1, T2, w.nchunk, w.ntA, w.ntB, WJ, w.groupA_f4,
+                           w.groupB_f4, distill_token, w.part_max, w.part_idx);
+    if (int rc = check_launch("k_scores_rowmax")) return rc;
+    prof_mark(2, st);
+
+    // 3. rank + select
+    int rc = TOME_OK;
+    for (int rep = 0; rep < prof_reps && rc == TOME_OK; ++rep)
+        rc = launch_select(w, WJ, true, n, T, re, class_token, distill_token, src_idx, dst_idx, unm_idx, node_max, row_map, st);
+    prof_mark(3, st);
+    g_prof.valid = g_prof.on && rc == TOME_OK;
+    return rc;
+}
 extern "C" int tome_match(const void *metric, int dtype, int64_t n, int64_t T, int64_t D, int64_t stride_n,
                           int64_t stride_t, int64_t r, int class_token, int distill_token, int64_t *src_idx,
                           int64_t *dst_idx, int64_t *unm_idx, float *node_max, int32_t *row_map,
@@ -1254,37 +1356,56 @@ extern "C" int tome_match(const void *metric, int dtype, int64_t n, int64_t T, i
     if (int rc = check_launch("k_unit_rows")) return rc;
     prof_mark(1, st);
 
-    // 2. similarity + row max/argmax: one single-wave workgroup per (group, A tile, j-part); the B tiles are
-    // split into WJ parts so that the launch has >= ~6 waves per SIMD (1024 SIMDs) whatever the batch
-    static const long target_waves = [] {
-        const char *e = getenv("TOME_SCORES_WAVES");  // tuning knob, default from measurements on MI355X
-        long v = e ? atol(e) : 0;
-        return v > 0 ? v : 6144L;
-    }();
-    int WJ = (int)((target_waves + n * w.ntA - 1) / (n * w.ntA));
-    if (WJ > MAX_WJ) WJ = MAX_WJ;
-    if (WJ > w.ntB) WJ = w.ntB;
-    if (WJ < 1) WJ = 1;
-    const unsigned nb2 = (unsigned)(((n + 7) / 8) * 8 * w.ntA * WJ);
-    for (int rep = 0; rep < prof_reps; ++rep)
-    if (w.nchunk == 1)
-        hipLaunchKernelGGL(k_scores_rowmax<true>, dim3(nb2), dim3(64), 0, st, (const f32x4 *)w.unitA,
-                           (const f32x4 *)w.unitB, (int)n, T1, T2, w.nchunk, w.ntA, w.ntB, WJ, w.groupA_f4,
-                           w.groupB_f4, distill_token, w.part_max, w.part_idx);
-    else
-        hipLaunchKernelGGL(k_scores_rowmax<false>, dim3(nb2), dim3(64), 0, st, (const f32x4 *)w.unitA,
-                           (const f32x4 *)w.unitB, (int)n, T1, T2, w.nchunk, w.ntA, w.ntB, WJ, w.groupA_f4,
-                           w.groupB_f4, distill_token, w.part_max, w.part_idx);
-    if (int rc = check_launch("k_scores_rowmax")) return rc;
-    prof_mark(2, st);
+    return match_tail(w, n, T, re, class_token, distill_token, src_idx, dst_idx, unm_idx, node_max, row_map, st);
+}
 
-    // 3. rank + select
-    int rc = TOME_OK;
-    for (int rep = 0; rep < prof_reps && rc == TOME_OK; ++rep)
-        rc = launch_select(w, WJ, true, n, T, re, class_token, distill_token, src_idx, dst_idx, unm_idx, node_max, row_map, st);
-    prof_mark(3, st);
-    g_prof.valid = g_prof.on && rc == TOME_OK;
-    return rc;
+extern "C" int tome_match_keys(const void *keys, int dtype, int64_t n, int64_t H, int64_t T, int64_t D,
+                               int64_t stride_n, int64_t stride_h, int64_t stride_t, int64_t r, int class_token,
+                               int distill_token, int64_t *src_idx, int64_t *dst_idx, int64_t *unm_idx,
+                               float *node_max, int32_t *row_map, void *workspace, size_t workspace_bytes,
+                               tome_stream_t stream) {
+    if (!keys || n <= 0 || T <= 0 || H <= 0) return fail(TOME_EINVAL, "tome_match_keys: bad shape/pointer");
+    if (D != 64) return fail(TOME_EINVAL, "tome_match_keys: head dimension %lld (only 64 is fused)", (long long)D);
+    if (n > 0x7fffffff / T) return fail(TOME_EINVAL, "tome_match_keys: problem too large");
+    const size_t es = dtype == TOME_F32 ? 4 : 2;
+    if (dtype < TOME_F32 || dtype > TOME_F16) return fail(TOME_EINVAL, "tome_match_keys: dtype %d", dtype);
+    if (((uintptr_t)keys) % 16 || (stride_n * es) % 16 || (stride_h * es) % 16 || (stride_t * es) % 16)
+        return fail(TOME_EINVAL, "tome_match_keys: keys must be 16-byte aligned in every stride");
+    const int64_t re = tome_effective_r(T, r, class_token, distill_token);
+    if (re <= 0) return TOME_OK;
+    if (!src_idx || !dst_idx || (!unm_idx && (T + 1) / 2 > re))
+        return fail(TOME_EINVAL, "tome_match_keys: null index buffer");
+    if (!workspace || workspace_bytes < tome_match_workspace_bytes(n, T, D))
+        return fail(TOME_EWORKSPACE, "tome_match_keys: workspace %zu < %zu bytes", workspace_bytes,
+                    tome_match_workspace_bytes(n, T, D));
+    if (((uintptr_t)workspace & 255) != 0) return fail(TOME_EINVAL, "tome_match_keys: workspace not 256-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    const MatchWs w = carve(workspace, n, T, D);
+    prof_mark(0, st);
+    const int prof_reps = g_prof.on ? g_prof.reps : 1;
+    const unsigned nb = (unsigned)((n * T + 31) / 32);
+    for (int rep = 0; rep < prof_reps; ++rep) {
+        switch (dtype) {
+        case TOME_F32:
+            hipLaunchKernelGGL(k_unit_rows_heads<float>, dim3(nb), dim3(256), 0, st, (const float *)keys, stride_n,
+                               stride_h, stride_t, (int)n, (int)H, (int)T, w.unitA, w.unitB, w.groupA_f4, w.groupB_f4,
+                               w.badA, w.badB);
+            break;
+        case TOME_BF16:
+            hipLaunchKernelGGL(k_unit_rows_heads<bf16_t>, dim3(nb), dim3(256), 0, st, (const bf16_t *)keys, stride_n,
+                               stride_h, stride_t, (int)n, (int)H, (int)T, w.unitA, w.unitB, w.groupA_f4, w.groupB_f4,
+                               w.badA, w.badB);
+            break;
+        default:
+            hipLaunchKernelGGL(k_unit_rows_heads<f16_t>, dim3(nb), dim3(256), 0, st, (const f16_t *)keys, stride_n,
+                               stride_h, stride_t, (int)n, (int)H, (int)T, w.unitA, w.unitB, w.groupA_f4, w.groupB_f4,
+                               w.badA, w.badB);
+            break;
+        }
+    }
+    if (int rc = check_launch("k_unit_rows_heads")) return rc;
+    prof_mark(1, st);
+    return match_tail(w, n, T, re, class_token, distill_token, src_idx, dst_idx, unm_idx, node_max, row_map, st);
 }
 
 extern "C" int tome_match_scores(const float *scores, int64_t n, int64_t T, int64_t r, int class_token,

@@ -16,6 +16,7 @@ LIB_PATH = os.environ.get("TOME_HIP_LIB", os.path.join(_PKG, "lib", "libtome_hip
 
 SYMBOLS = (
     "tome_abi_version", "tome_last_error", "tome_effective_r", "tome_match_workspace_bytes", "tome_match",
+    "tome_match_keys",
     "tome_match_scores", "tome_edge_keep", "tome_merge_wavg", "tome_merge_wavg_regrouped", "tome_merge", "tome_drop",
     "tome_unmerge",
     "tome_profile_enable", "tome_profile_read",
@@ -54,6 +55,9 @@ def lib() -> ctypes.CDLL:
     L.tome_match_workspace_bytes.argtypes = [i64, i64, i64]
     L.tome_match.restype = i32
     L.tome_match.argtypes = [vp, i32, i64, i64, i64, i64, i64, i64, i32, i32, vp, vp, vp, vp, vp, vp, sz, vp]
+    L.tome_match_keys.restype = i32
+    L.tome_match_keys.argtypes = [vp, i32, i64, i64, i64, i64, i64, i64, i64, i64, i32, i32, vp, vp, vp, vp, vp, vp, sz,
+                                  vp]
     L.tome_match_scores.restype = i32
     L.tome_match_scores.argtypes = [vp, i64, i64, i64, i32, i32, vp, vp, vp, vp, vp, vp, sz, vp]
     L.tome_edge_keep.restype = i32
@@ -173,6 +177,39 @@ def match(metric: torch.Tensor, r: int, class_token=False, distill_token=False, 
                           plan.dst_idx.data_ptr(), plan.unm_idx.data_ptr(), _ptr(plan.node_max), _ptr(plan.row_map),
                           ws.data_ptr(), ws.numel(), st)
     _check(rc, "tome_match")
+    return plan
+
+
+def keys_fusable(keys: torch.Tensor) -> bool:
+    """Can tome_match_keys read this [n,H,T,64] key tensor in place?"""
+    if keys.dim() != 4 or keys.shape[-1] != 64 or keys.stride(3) != 1 or keys.dtype not in DTYPES or not keys.is_cuda:
+        return False
+    es = keys.element_size()
+    return keys.data_ptr() % 16 == 0 and all((keys.stride(d) * es) % 16 == 0 for d in range(3))
+
+
+def match_keys(keys: torch.Tensor, r: int, class_token=False, distill_token=False, want_node_max=False,
+               want_row_map=False) -> Optional[MatchPlan]:
+    """tome_match_keys on per-head keys [n,H,T,64] (metric = keys.mean(1) is never materialised)."""
+    require_device(keys, "match_keys(keys)")
+    if not keys_fusable(keys):
+        raise TomeHipError(f"match_keys: keys {tuple(keys.shape)} strides {keys.stride()} are not readable in place")
+    n, H, T, D = keys.shape
+    re = effective_r(T, r, class_token, distill_token)
+    if re <= 0 or n == 0:
+        return None
+    L = lib()
+    dev = keys.device
+    with torch.cuda.device(dev):
+        st = _stream(dev)
+        nbytes = L.tome_match_workspace_bytes(n, T, D)
+        ws = _workspace(dev, st, nbytes)
+        plan = _alloc_plan(n, T, re, class_token, distill_token, dev, want_node_max, want_row_map)
+        rc = L.tome_match_keys(keys.data_ptr(), DTYPES[keys.dtype], n, H, T, D, keys.stride(0), keys.stride(1),
+                               keys.stride(2), int(r), int(bool(class_token)), int(bool(distill_token)),
+                               plan.src_idx.data_ptr(), plan.dst_idx.data_ptr(), plan.unm_idx.data_ptr(),
+                               _ptr(plan.node_max), _ptr(plan.row_map), ws.data_ptr(), ws.numel(), st)
+    _check(rc, "tome_match_keys")
     return plan
 
 

@@ -29,6 +29,31 @@ def do_nothing(x, mode=None):
     return x
 
 
+class HeadMeanKeys:
+    """The metric ``k.mean(1)`` kept as a promise: holds the per-head keys [n,H,T,64] (a view of the attention's
+    qkv buffer).  The matching functions of this module read the keys in place (tome_match_keys: head mean,
+    unit vectors, similarity in one pass over them); anything else that wants the tensor calls
+    ``.materialize()``.  Shape queries behave like the metric's."""
+
+    def __init__(self, keys: torch.Tensor):
+        self.keys = keys
+
+    @property
+    def shape(self):
+        n, _, t, d = self.keys.shape
+        return torch.Size((n, t, d))
+
+    @property
+    def device(self):
+        return self.keys.device
+
+    def size(self, dim=None):
+        return self.shape if dim is None else self.shape[dim]
+
+    def materialize(self) -> torch.Tensor:
+        return self.keys.mean(1)
+
+
 def _scores_for_random(metric: torch.Tensor) -> torch.Tensor:
     """merge.py:54-57 / :239-242 -- the random variants replace the similarity by uniform noise drawn on
     the metric's device (torch's generator, exactly as the reference draws it)."""
@@ -39,6 +64,10 @@ def _scores_for_random(metric: torch.Tensor) -> torch.Tensor:
 
 def _plan(metric, r, class_token, distill_token, random: bool, **want) -> Optional[_abi.MatchPlan]:
     with torch.no_grad():
+        if isinstance(metric, HeadMeanKeys):
+            if not random and _abi.keys_fusable(metric.keys):
+                return _abi.match_keys(metric.keys, r, class_token, distill_token, **want)
+            metric = metric.materialize()
         if random:
             _abi.require_device(metric, "bipartite_soft_matching(metric)")
             t = metric.shape[1]

@@ -7,6 +7,7 @@ import torch
 import torch.nn.functional as F
 
 from . import _common as C
+from ..merge import HeadMeanKeys
 
 
 def _block_forward(self, x, B, T, W):
@@ -52,7 +53,7 @@ def _attention_forward(self, x, size: torch.Tensor = None):
     out = out.transpose(1, 2).reshape(B, N, Cc)
     if self.with_qkv:
         out = self.proj_drop(self.proj(out))
-    return out, k.mean(1)[:, 1:, :]
+    return out, HeadMeanKeys(k[:, :, 1:, :])  # k.mean(1)[:, 1:, :] averaged inside the matching kernel
 
 
 def _regroup(x, B, T, P):

@@ -12,6 +12,7 @@ import torch
 import torch.nn.functional as F
 
 from . import _common as C
+from ..merge import HeadMeanKeys
 
 
 def _block_forward(self, x):
@@ -51,7 +52,7 @@ def _attention_forward(self, x, size: torch.Tensor = None, head_aggregation: str
     out = F.scaled_dot_product_attention(q, k, v, attn_mask=attn_bias, dropout_p=drop_p, scale=self.scale)
     out = self.proj_drop(self.proj(out.transpose(1, 2).reshape(B, N, -1)))
     if head_aggregation == "mean":
-        metric = k.mean(1)
+        metric = HeadMeanKeys(k)  # k.mean(1), averaged inside the matching kernel when the layer merges
     elif head_aggregation == "concat":
         metric = k.transpose(1, 2).reshape(B, N, -1)
     else:

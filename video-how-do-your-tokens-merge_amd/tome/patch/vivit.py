@@ -10,6 +10,7 @@ import torch
 import torch.nn.functional as F
 
 from . import _common as C
+from ..merge import HeadMeanKeys
 
 
 def _layer_forward(self, hidden_states, head_mask=None, output_attentions=False):
@@ -69,7 +70,7 @@ def _self_attention_forward(self, hidden_states, size=None, head_aggregation="me
         ctx = F.scaled_dot_product_attention(q, k, v, attn_mask=bias, dropout_p=drop_p)
     ctx = ctx.permute(0, 2, 1, 3).reshape(B, N, H * hd)
     if head_aggregation == "mean":
-        metric = k.mean(1)
+        metric = HeadMeanKeys(k)  # k.mean(1), averaged inside the matching kernel when the layer merges
     elif head_aggregation == "concat":
         metric = k.transpose(1, 2).reshape(B, N, -1)
     else:
