@@ -45,7 +45,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=32, help="clips per GPU per step")
+    ap.add_argument("--batch", type=int, default=64, help="clips per GPU per step")
     ap.add_argument("--frames", type=int, default=16)
     ap.add_argument("--r", type=int, default=16)
     ap.add_argument("--cpu-clips", type=int, default=2, help="batch of the CPU baseline sample")

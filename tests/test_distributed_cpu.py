@@ -67,3 +67,31 @@ def test_shard_range_properties():
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             sizes = [hi - lo for lo, hi in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_clip_ensemble_meter_matches_per_clip_loop():
+    """ClipEnsembleMeter == the per-clip accumulation loop of slowfast's TestMeter (sum and max ensembling),
+    fed in shuffled batches."""
+    from hosts.evalloop import ClipEnsembleMeter
+    g = torch.Generator().manual_seed(5)
+    V, K, C = 23, 3, 11
+    preds = torch.randn(V * K, C, generator=g)
+    labels = torch.randint(0, C, (V,), generator=g).repeat_interleave(K)
+    clip_ids = torch.arange(V * K)
+    perm = torch.randperm(V * K, generator=g)
+    for method in ("sum", "max"):
+        meter = ClipEnsembleMeter(V, K, C, ensemble_method=method)
+        for a in range(0, V * K, 7):
+            idx = perm[a:a + 7]
+            meter.update(preds[idx], labels[idx], clip_ids[idx])
+        ref = torch.zeros(V, C)
+        for i in range(V * K):  # the reference's loop (meters.py:337-358)
+            v = int(clip_ids[i]) // K
+            ref[v] = ref[v] + preds[i] if method == "sum" else torch.max(ref[v], preds[i])
+        assert torch.allclose(meter.video_preds, ref, atol=1e-6)
+        stats = meter.finalize()
+        top = ref.topk(5, dim=1).indices
+        lab = labels[::K]
+        assert stats["videos"] == V and stats["all_clips_seen"]
+        assert abs(stats["top1_acc"] - 100.0 * (top[:, 0] == lab).float().mean().item()) < 1e-4
+        assert abs(stats["top5_acc"] - 100.0 * (top == lab[:, None]).any(1).float().mean().item()) < 1e-4

@@ -32,7 +32,7 @@ def load(d):
 def main():
     fetch = load(sys.argv[1])
     write = load(sys.argv[2])
-    out = {"_units": "bytes per launch (mean over the launches of one 12-layer chain, batch 32)",
+    out = {"_units": "bytes per launch (mean over the launches of one 12-layer chain, batch 64)",
            "_correction": "FETCH_SIZE KiB x2 (gfx950 wide-read under-count) + WRITE_SIZE KiB"}
     for k in fetch:
         f = sum(v for v, _ in fetch[k]) / len(fetch[k]) * 1024 * 2

@@ -13,7 +13,7 @@ import torch  # noqa: E402
 
 import bench  # noqa: E402
 
-batch = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+batch = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 with torch.no_grad():
     stats = bench.measure_kernels(batch, 1568, 16, torch.device("cuda", 0), reps=2)
 torch.cuda.synchronize()

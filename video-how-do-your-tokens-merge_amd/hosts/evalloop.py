@@ -30,3 +30,43 @@ def all_reduce_counts(counts: torch.Tensor) -> torch.Tensor:
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         dist.all_reduce(counts, op=dist.ReduceOp.SUM)
     return counts
+
+
+class ClipEnsembleMeter:
+    """Multi-view test ensembling with the semantics of slowfast's TestMeter (slowfast/utils/meters.py:324-359,
+    395-436): every video is seen through `num_clips` clips (clip id = video id * num_clips + view), clip
+    predictions are summed (or max-ed) per video, top-k is counted on the ensembled scores.  Vectorised and
+    device-resident (no per-clip Python loop, no all-gather of logits): a rank owns whole videos
+    (`shard_range` over videos), counts locally, and `finalize` does the one all-reduce."""
+
+    def __init__(self, num_videos: int, num_clips: int, num_classes: int, device="cpu", ensemble_method: str = "sum"):
+        if ensemble_method not in ("sum", "max"):
+            raise NotImplementedError(f"Ensemble Method {ensemble_method} is not supported")
+        self.num_videos, self.num_clips, self.method = num_videos, num_clips, ensemble_method
+        self.video_preds = torch.zeros((num_videos, num_classes), device=device)
+        self.video_labels = torch.zeros((num_videos,), dtype=torch.long, device=device)
+        self.clip_count = torch.zeros((num_videos,), dtype=torch.long, device=device)
+
+    @torch.no_grad()
+    def update(self, preds: torch.Tensor, labels: torch.Tensor, clip_ids: torch.Tensor) -> None:
+        vid = torch.div(clip_ids.to(self.video_preds.device).long(), self.num_clips, rounding_mode="floor")
+        preds = preds.to(self.video_preds.device, torch.float32)
+        if self.method == "sum":
+            self.video_preds.index_add_(0, vid, preds)
+        else:
+            self.video_preds.scatter_reduce_(0, vid[:, None].expand_as(preds), preds, reduce="amax", include_self=True)
+        self.video_labels[vid] = labels.to(self.video_labels.device).long()
+        self.clip_count.index_add_(0, vid, torch.ones_like(vid))
+
+    @torch.no_grad()
+    def finalize(self, ks=(1, 5), videos=None) -> dict:
+        """Top-k accuracies (percent) over the videos this meter owns (`videos` = (lo, hi) shard, default all),
+        reduced over ranks by ONE all-reduce of the counts."""
+        lo, hi = videos if videos is not None else (0, self.num_videos)
+        counts = topk_counts(self.video_preds[lo:hi], self.video_labels[lo:hi], ks)
+        complete = bool((self.clip_count[lo:hi] == self.num_clips).all())
+        counts = all_reduce_counts(counts)
+        total = max(1, int(counts[-1].item()))
+        out = {f"top{k}_acc": 100.0 * int(counts[i].item()) / total for i, k in enumerate(ks)}
+        out.update(videos=int(counts[-1].item()), all_clips_seen=complete)
+        return out
