@@ -36,6 +36,7 @@ def test_effective_r_matches_reference_clamp():
                 for dist in (False, True):
                     want = max(0, min(r, (T - cls - dist) // 2))  # merge.py:36-47
                     assert _abi.effective_r(T, r, cls, dist) == want
+                    assert _abi.lib().tome_effective_r(T, r, int(cls), int(dist)) == want
 
 
 def test_workspace_bytes_monotone_and_aligned():

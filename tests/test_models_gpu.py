@@ -158,3 +158,26 @@ def test_duplicate_layer_patches():
     with torch.no_grad():
         out = model([torch.rand(2, 3, 4, 32, 32, device=DEV)])
     assert torch.isfinite(out).all() and model._tome_info["size"].shape[1] == 32 - 10
+
+
+def test_graphed_forward_replays_the_merge_path():
+    """The whole patched forward, merge kernels included, captured in a HIP graph and replayed on new clips:
+    same logits as the eager run (the merge path launches on torch's current stream, allocates through
+    torch and never synchronises, so it is capturable)."""
+    tome, H = _hosts()
+    from hosts.graphed import GraphedForward
+    torch.manual_seed(0)
+    model = H["videomae"].VideoMAE(num_frames=8, img_size=64, patch_size=16, embed_dim=64, depth=4, num_heads=1,
+                                   num_classes=9).to(DEV).eval()
+    tome.patch.videomae(model)
+    model.r = 6
+    a = torch.rand(2, 3, 8, 64, 64, device=DEV)
+    b = torch.rand(2, 3, 8, 64, 64, device=DEV)
+    fwd = GraphedForward(model, [a])
+    with torch.no_grad():
+        want_b = model([b]).clone()
+        want_a = model([a]).clone()
+    got_b = fwd([b]).clone()
+    got_a = fwd([a]).clone()
+    assert torch.equal(got_b, want_b) and torch.equal(got_a, want_a)
+    assert not torch.equal(got_a, got_b)

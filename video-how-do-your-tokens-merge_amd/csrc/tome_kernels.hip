@@ -1302,8 +1302,6 @@ extern "C" int tome_match(const void *metric, int dtype, int64_t n, int64_t T, i
     if (((uintptr_t)workspace & 255) != 0) return fail(TOME_EINVAL, "tome_match: workspace not 256-byte aligned");
     hipStream_t st = (hipStream_t)stream;
     const MatchWs w = carve(workspace, n, T, D);
-    const int T1 = (int)((T + 1) / 2), T2 = (int)(T / 2);
-
     // 1. unit vectors
     prof_mark(0, st);
     const size_t es = dtype == TOME_F32 ? 4 : 2;

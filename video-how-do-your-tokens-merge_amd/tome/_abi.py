@@ -105,6 +105,26 @@ def _stream(device) -> int:
     return torch.cuda.current_stream(device).cuda_stream
 
 
+class _on_device:
+    """`with torch.cuda.device(dev)` without its cost when `dev` already is the current device (the
+    common case: one process per GPU)."""
+
+    __slots__ = ("idx", "prev")
+
+    def __init__(self, device):
+        self.idx = device.index
+
+    def __enter__(self):
+        self.prev = torch.cuda.current_device()
+        if self.prev != self.idx:
+            torch.cuda.set_device(self.idx)
+
+    def __exit__(self, *exc):
+        if self.prev != self.idx:
+            torch.cuda.set_device(self.prev)
+        return False
+
+
 _workspaces = {}
 
 
@@ -118,7 +138,8 @@ def _workspace(device, stream: int, nbytes: int) -> torch.Tensor:
 
 
 def effective_r(T: int, r: int, class_token: bool, distill_token: bool) -> int:
-    return int(lib().tome_effective_r(int(T), int(r), int(bool(class_token)), int(bool(distill_token))))
+    """merge.py:36-47 (same clamp as tome_effective_r; tests hold the two together)."""
+    return max(0, min(int(r), (int(T) - int(bool(class_token)) - int(bool(distill_token))) // 2))
 
 
 class MatchPlan:
@@ -167,7 +188,7 @@ def match(metric: torch.Tensor, r: int, class_token=False, distill_token=False, 
         metric = metric.contiguous()
     L = lib()
     dev = metric.device
-    with torch.cuda.device(dev):
+    with _on_device(dev):
         st = _stream(dev)
         nbytes = L.tome_match_workspace_bytes(n, T, D)
         ws = _workspace(dev, st, nbytes)
@@ -189,10 +210,10 @@ def keys_fusable(keys: torch.Tensor) -> bool:
 
 
 def match_keys(keys: torch.Tensor, r: int, class_token=False, distill_token=False, want_node_max=False,
-               want_row_map=False) -> Optional[MatchPlan]:
+               want_row_map=False, checked: bool = False) -> Optional[MatchPlan]:
     """tome_match_keys on per-head keys [n,H,T,64] (metric = keys.mean(1) is never materialised)."""
-    require_device(keys, "match_keys(keys)")
-    if not keys_fusable(keys):
+    if not checked and not keys_fusable(keys):
+        require_device(keys, "match_keys(keys)")
         raise TomeHipError(f"match_keys: keys {tuple(keys.shape)} strides {keys.stride()} are not readable in place")
     n, H, T, D = keys.shape
     re = effective_r(T, r, class_token, distill_token)
@@ -200,7 +221,7 @@ def match_keys(keys: torch.Tensor, r: int, class_token=False, distill_token=Fals
         return None
     L = lib()
     dev = keys.device
-    with torch.cuda.device(dev):
+    with _on_device(dev):
         st = _stream(dev)
         nbytes = L.tome_match_workspace_bytes(n, T, D)
         ws = _workspace(dev, st, nbytes)
@@ -225,7 +246,7 @@ def match_scores(scores: torch.Tensor, T: int, r: int, class_token=False, distil
     scores = scores.float().contiguous()
     L = lib()
     dev = scores.device
-    with torch.cuda.device(dev):
+    with _on_device(dev):
         st = _stream(dev)
         nbytes = L.tome_match_workspace_bytes(n, T, 1)
         ws = _workspace(dev, st, nbytes)
@@ -241,7 +262,7 @@ def edge_keep(plan: MatchPlan, threshold: float) -> torch.Tensor:
     if plan.node_max is None:
         raise TomeHipError("edge_keep needs a plan made with want_node_max=True")
     keep = torch.empty((plan.n, plan.r), dtype=torch.uint8, device=plan.device)
-    with torch.cuda.device(plan.device):
+    with _on_device(plan.device):
         rc = lib().tome_edge_keep(plan.node_max.data_ptr(), plan.src_idx.data_ptr(), plan.n, plan.T, plan.r,
                                   float(threshold), keep.data_ptr(), _stream(plan.device))
     _check(rc, "tome_edge_keep")
@@ -277,7 +298,7 @@ def merge_wavg(plan: MatchPlan, x: torch.Tensor, size: Optional[torch.Tensor]):
     scode = DTYPES[sdtype]
     x_out = torch.empty((n, T - plan.r, C), dtype=x.dtype, device=x.device)
     s_out = torch.empty((n, T - plan.r, 1), dtype=sdtype, device=x.device)
-    with torch.cuda.device(x.device):
+    with _on_device(x.device):
         rc = lib().tome_merge_wavg(x.data_ptr(), xcode, _ptr(size), scode, n, T, C, plan.r, plan.src_idx.data_ptr(),
                                    plan.dst_idx.data_ptr(), plan.unm_idx.data_ptr(), int(plan.distill_token),
                                    _ptr(plan.edge_keep), x_out.data_ptr(), s_out.data_ptr(), _stream(x.device))
@@ -316,7 +337,7 @@ def merge_wavg_regrouped(plan: MatchPlan, x_full: torch.Tensor, size: Optional[t
         sdtype = x_full.dtype
     x_out = torch.empty((B, cls + (P - plan.r) * F, C), dtype=x_full.dtype, device=x_full.device)
     s_out = torch.empty((plan.n, P - plan.r, 1), dtype=sdtype, device=x_full.device)
-    with torch.cuda.device(x_full.device):
+    with _on_device(x_full.device):
         rc = lib().tome_merge_wavg_regrouped(x_full.data_ptr(), xcode, _ptr(size), DTYPES[sdtype], B, F, P, C, plan.r,
                                              cls, plan.src_idx.data_ptr(), plan.dst_idx.data_ptr(),
                                              plan.unm_idx.data_ptr(), _ptr(plan.edge_keep), x_out.data_ptr(),
@@ -331,7 +352,7 @@ def merge(plan: MatchPlan, x: torch.Tensor, mode: str) -> torch.Tensor:
     x = _prep_x(plan, x, "merge(x)", plan.T)
     n, T, C = x.shape
     out = torch.empty((n, T - plan.r, C), dtype=x.dtype, device=x.device)
-    with torch.cuda.device(x.device):
+    with _on_device(x.device):
         rc = lib().tome_merge(x.data_ptr(), dtype_code(x, "x"), n, T, C, plan.r, plan.src_idx.data_ptr(),
                               plan.dst_idx.data_ptr(), plan.unm_idx.data_ptr(), int(plan.distill_token), MODES[mode],
                               _ptr(plan.edge_keep), out.data_ptr(), _stream(x.device))
@@ -343,7 +364,7 @@ def drop(plan: MatchPlan, x: torch.Tensor) -> torch.Tensor:
     x = _prep_x(plan, x, "drop(x)", plan.T)
     n, T, C = x.shape
     out = torch.empty((n, T - plan.r, C), dtype=x.dtype, device=x.device)
-    with torch.cuda.device(x.device):
+    with _on_device(x.device):
         rc = lib().tome_drop(x.data_ptr(), dtype_code(x, "x"), n, T, C, plan.r, plan.unm_idx.data_ptr(),
                              int(plan.distill_token), out.data_ptr(), _stream(x.device))
     _check(rc, "tome_drop")
@@ -354,7 +375,7 @@ def unmerge(plan: MatchPlan, x: torch.Tensor) -> torch.Tensor:
     x = _prep_x(plan, x, "unmerge(x)", plan.T - plan.r)
     n, _, C = x.shape
     out = torch.empty((n, plan.T, C), dtype=x.dtype, device=x.device)
-    with torch.cuda.device(x.device):
+    with _on_device(x.device):
         rc = lib().tome_unmerge(x.data_ptr(), dtype_code(x, "x"), n, plan.T, C, plan.r, plan.src_idx.data_ptr(),
                                 plan.dst_idx.data_ptr(), plan.unm_idx.data_ptr(), out.data_ptr(), _stream(x.device))
     _check(rc, "tome_unmerge")

@@ -66,7 +66,7 @@ def _plan(metric, r, class_token, distill_token, random: bool, **want) -> Option
     with torch.no_grad():
         if isinstance(metric, HeadMeanKeys):
             if not random and _abi.keys_fusable(metric.keys):
-                return _abi.match_keys(metric.keys, r, class_token, distill_token, **want)
+                return _abi.match_keys(metric.keys, r, class_token, distill_token, checked=True, **want)
             metric = metric.materialize()
         if random:
             _abi.require_device(metric, "bipartite_soft_matching(metric)")
