@@ -398,3 +398,21 @@ def test_match_keys_fused_head_mean(dtype, cls):
     plan = oracle.match(mean[:, 1:, :], 16, False, False)
     got = _abi.match_keys(sl, 16)
     np.testing.assert_array_equal(got.unm_idx.cpu().numpy(), plan.unm_idx)
+
+
+def test_empty_and_degenerate_inputs():
+    """Empty batch, single token, r larger than anything, r = 0: the do_nothing pair, as merge.py:46-47."""
+    tm = _tome()
+    for shape, r in [((0, 16, 8), 4), ((2, 1, 8), 4), ((2, 16, 8), 0), ((2, 16, 8), -3), ((2, 1, 8), 0)]:
+        merge, unmerge = tm.bipartite_soft_matching(torch.zeros(shape, device=DEV), r)
+        assert merge is tm.do_nothing and unmerge is tm.do_nothing
+        x = torch.randn(shape[0], shape[1], 4, device=DEV)
+        xo, so = tm.merge_wavg(merge, x)
+        assert xo.shape == x.shape and so.shape == (shape[0], shape[1], 1)
+    # class token alone protects the only pair: T=2 with cls -> (2-1)//2 = 0
+    merge, _ = tm.bipartite_soft_matching(torch.randn(2, 2, 8, device=DEV), 5, class_token=True)
+    assert merge is tm.do_nothing
+    # T=3 with cls: one merge possible, class token (A row 0) must survive
+    merge, _ = tm.bipartite_soft_matching(torch.randn(2, 3, 8, device=DEV), 5, class_token=True)
+    p = merge.plan
+    assert p.r == 1 and bool((p.src_idx == 1).all()) and bool((p.unm_idx == 0).all())
