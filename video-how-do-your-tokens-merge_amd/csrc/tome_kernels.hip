@@ -978,8 +978,12 @@ __global__ __launch_bounds__(256) void k_merge_rows_fast(const TX *__restrict__ 
     const TS *sg = size ? size + (int64_t)g * T_ : nullptr;
     const int64_t *dstg = dst_idx ? dst_idx + (int64_t)g * r : nullptr;
 
-    // per-row facts, computed by lanes 0..R-1 in parallel (one index load, then one size load) and
-    // broadcast as wave-uniform scalars: source token, size, B-row number, "something merges into it"
+    // per-row facts, computed by lanes 0..R-1 in parallel and broadcast as wave-uniform scalars: source
+    // token, B-row number, "something merges into it", size.  Load order matters for latency: the first block
+    // of dst_idx and the unm_idx entries go out together; the sizes are requested as soon as the tokens are
+    // known but only READ after the token rows' own loads have been issued, so a wave waits for two memory
+    // round trips (index -> rows), not three.
+    const int d_first = (OP != OP_DROP && lane < r) ? (int)dstg[lane] : -2;
     int my_tok = 0, my_j = -1;
     float my_s = 1.0f;
     bool my_valid = false;
@@ -996,21 +1000,23 @@ __global__ __launch_bounds__(256) void k_merge_rows_fast(const TX *__restrict__ 
             } else {
                 my_tok = 2 * (int)unm_idx[(int64_t)g * U + idx];
             }
-            if (OP == OP_WAVG && sg) my_s = to_f32(sg[my_tok]);
         }
     }
+    TS my_s_raw;
+    const bool load_size = (OP == OP_WAVG) && sg && my_valid;
+    if (load_size) my_s_raw = sg[my_tok];
     const unsigned long long vmask = __ballot(my_valid);
     const int tok0 = __builtin_amdgcn_readlane(my_tok, 0), tok1 = __builtin_amdgcn_readlane(my_tok, 1),
               tok2 = __builtin_amdgcn_readlane(my_tok, 2), tok3 = __builtin_amdgcn_readlane(my_tok, 3);
     const int j0 = __builtin_amdgcn_readlane(my_j, 0), j1 = __builtin_amdgcn_readlane(my_j, 1),
               j2 = __builtin_amdgcn_readlane(my_j, 2), j3 = __builtin_amdgcn_readlane(my_j, 3);
-    const float sz0 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(my_s), 0)),
-                sz1 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(my_s), 1)),
-                sz2 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(my_s), 2)),
-                sz3 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(my_s), 3));
     bool e0 = false, e1 = false, e2 = false, e3 = false;  // rows that receive sources
     if (OP != OP_DROP) {
-        for (int base = 0; base < r; base += WAVE) {
+        e0 = __ballot(d_first == j0) != 0ull;
+        e1 = __ballot(d_first == j1) != 0ull;
+        e2 = __ballot(d_first == j2) != 0ull;
+        e3 = __ballot(d_first == j3) != 0ull;
+        for (int base = WAVE; base < r; base += WAVE) {
             const int k = base + lane;
             const int d = (k < r) ? (int)dstg[k] : -2;
             e0 = e0 || (__ballot(d == j0) != 0ull);
@@ -1038,6 +1044,11 @@ __global__ __launch_bounds__(256) void k_merge_rows_fast(const TX *__restrict__ 
             raw[it] = *reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(xg + (int64_t)t * lin.tok_stride) +
                                                        cc * 16);
     }
+    if (load_size) my_s = to_f32(my_s_raw);
+    const float sz0 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(my_s), 0)),
+                sz1 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(my_s), 1)),
+                sz2 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(my_s), 2)),
+                sz3 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(my_s), 3));
     // (x*s)/s is x itself when s is 1, and also when s is a power of two and x came from a 16-bit
     // format (the fp32 product cannot overflow): those rows move as raw bits
     constexpr bool narrow = sizeof(TX) == 2;
