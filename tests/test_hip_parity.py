@@ -416,3 +416,53 @@ def test_empty_and_degenerate_inputs():
     merge, _ = tm.bipartite_soft_matching(torch.randn(2, 3, 8, device=DEV), 5, class_token=True)
     p = merge.plan
     assert p.r == 1 and bool((p.src_idx == 1).all()) and bool((p.unm_idx == 0).all())
+
+
+def _fuzz_cases(count, seed):
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(count):
+        n = int(rng.choice([1, 2, 3, 5, 9, 17]))
+        T = int(rng.choice([2, 3, 7, 31, 32, 33, 63, 64, 65, 66, 129, 130, 195, 196, 197, 392, 500, 784]))
+        D = int(rng.choice([8, 16, 24, 64, 64, 64, 72, 128, 192]))
+        C = int(rng.choice([1, 3, 8, 12, 64, 96, 768, 772]))
+        r = int(rng.choice([1, 2, 5, 16, 17, 63, 64, 65, 100, 10 ** 6]))
+        cls = bool(rng.integers(0, 2))
+        dtype = [torch.float32, torch.bfloat16, torch.float16][int(rng.integers(0, 3))]
+        sized = bool(rng.integers(0, 2))
+        kind = "clustered" if rng.integers(0, 3) == 0 else "normal"
+        out.append((n, T, D, C, r, cls, dtype, sized, kind, int(rng.integers(1, 1 << 30))))
+    return out
+
+
+@pytest.mark.parametrize("case", _fuzz_cases(48, 20260104), ids=lambda c: f"n{c[0]}T{c[1]}D{c[2]}C{c[3]}r{c[4]}")
+def test_fuzz_against_oracle(case):
+    """Seeded random shapes (ragged tiles, D and C off every grid, r from 1 to 'everything', class token,
+    three dtypes, tie-heavy keys): matching bit-exact vs the oracle, merge_wavg / sum / amax / unmerge equal
+    to the oracle's fp32 result rounded once to the tensor dtype."""
+    from tome import _abi
+    n, T, D, C, r, cls, dtype, sized, kind, seed = case
+    tm = _tome()
+    metric = (synth.clustered if kind == "clustered" else synth.normal_like)((n, T, D), seed)
+    m_dev = dev(metric, dtype)
+    m_host = host(m_dev)
+    plan = oracle.match(m_host, r, cls, False)
+    merge, unmerge = tm.bipartite_soft_matching(m_dev, r, cls)
+    if plan is None:
+        assert merge is tm.do_nothing
+        return
+    p = merge.plan
+    np.testing.assert_array_equal(p.src_idx.cpu().numpy(), plan.src_idx)
+    np.testing.assert_array_equal(p.dst_idx.cpu().numpy(), plan.dst_idx)
+    np.testing.assert_array_equal(p.unm_idx.cpu().numpy(), plan.unm_idx)
+    x = dev(synth.normal_like((n, T, C), seed ^ 0x77), dtype)
+    size = dev(synth.small_ints((n, T, 1), seed ^ 0x99, 1, 6), dtype) if sized else None
+    xo, so = tm.merge_wavg(merge, x, size)
+    want_x, want_s = oracle.merge_wavg(plan, host(x), None if size is None else host(size))
+    assert torch.equal(xo.cpu(), torch.from_numpy(want_x).to(dtype)), "merge_wavg x"
+    assert torch.equal(so.cpu(), torch.from_numpy(want_s).to(dtype)), "merge_wavg size"
+    for mode in ("sum", "amax"):
+        got = merge(x, mode=mode)
+        assert torch.equal(got.cpu(), torch.from_numpy(oracle.merge(plan, host(x), mode)).to(dtype)), mode
+    back = unmerge(xo)
+    assert torch.equal(back.cpu(), torch.from_numpy(oracle.unmerge(plan, host(xo))).to(dtype)), "unmerge"
