@@ -466,3 +466,22 @@ def test_fuzz_against_oracle(case):
         assert torch.equal(got.cpu(), torch.from_numpy(oracle.merge(plan, host(x), mode)).to(dtype)), mode
     back = unmerge(xo)
     assert torch.equal(back.cpu(), torch.from_numpy(oracle.unmerge(plan, host(xo))).to(dtype)), "unmerge"
+
+
+def test_unused_variants_shapes():
+    """kth_ / random_bipartite_soft_matching (merge.py:105-212; no patch calls them): token counts, conservation
+    under 'sum', unmerge shape -- and they refuse CPU tensors like the rest of the package."""
+    tm = _tome()
+    from tome._abi import TomeHipError
+    x = torch.randn(2, 30, 8, device=DEV)
+    merge, unmerge = tm.kth_bipartite_soft_matching(x, 3)
+    out = merge(x, mode="sum")
+    assert out.shape == (2, 10, 8) and torch.allclose(out.sum(1), x.sum(1), atol=1e-4)
+    assert unmerge(merge(x)).shape == x.shape
+    torch.manual_seed(1)
+    merge, unmerge = tm.random_bipartite_soft_matching(x, 7)
+    out = merge(x, mode="sum")
+    assert out.shape == (2, 23, 8) and torch.allclose(out.sum(1), x.sum(1), atol=1e-4)
+    assert unmerge(merge(x)).shape == x.shape
+    with pytest.raises(TomeHipError):
+        tm.kth_bipartite_soft_matching(torch.randn(1, 8, 4), 2)
