@@ -8,7 +8,7 @@ import sys
 import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = os.path.join(ROOT, "video-how-do-your-tokens-merge_amd", "csrc", "tome_kernels.hip")
+SRC = os.path.join(ROOT, "video-how-do-your-tokens-merge_amd", "csrc", "tome_kernels.hip")  # includes tome_*.h
 
 
 def main():

@@ -1,0 +1,509 @@
+// tome_merge.h -- part of the single translation unit csrc/tome_kernels.hip (merge / unmerge row kernels).
+#pragma once
+// ------------------------------------------------------------------------------------------------
+// k_merge_rows: merge.py:75-85 (+ :365-368 when OP_WAVG).  One wave per OUTPUT row; the wave finds
+// the sources of a destination row by ballot-scanning dst_idx (r entries, rank order), so the sum is
+// atomic-free and in the contract's order.  Every input row is read once, every output row written once.
+// ------------------------------------------------------------------------------------------------
+enum { OP_WAVG = 100, OP_DROP = 101 };
+
+template <int OP> __device__ __forceinline__ float reduce_step(float acc, float v) {
+    if (OP == TOME_SUM || OP == TOME_MEAN || OP == OP_WAVG) return __fadd_rn(acc, v);
+    if (OP == TOME_PROD) return __fmul_rn(acc, v);
+    if (OP == TOME_AMAX) return (acc != acc) ? acc : (!(v <= acc) ? v : acc);
+    if (OP == TOME_AMIN) return (acc != acc) ? acc : (!(v >= acc) ? v : acc);
+    return acc;
+}
+
+// Where the token rows of group g live.  Contiguous [n,T,C] is {0, T*C, 0, C, 1}; the regrouped views of
+// TimeSformer / Motionformer ('b (p t) m -> (b t) p m', timesformer.py:89-90; 'b (s f) d -> (b f) s d',
+// motionformer.py:150-151) are {cls*C, (cls+P*F)*C, C, F*C, F}: no permuted copy of x is ever made.
+struct TokLayout {
+    int64_t base, outer_stride, inner_stride, tok_stride;  // elements
+    int inner;                                             // groups per outer index
+};
+
+template <typename TX> __device__ __forceinline__ TX *group_ptr(TX *p, const TokLayout &L, int g) {
+    return p + L.base + (int64_t)(g / L.inner) * L.outer_stride + (int64_t)(g % L.inner) * L.inner_stride;
+}
+
+// One destination row (odd token 2j+1 plus every source merged into it), whole wave, contract order:
+// own term first, then the sources in src_idx (rank) order found by ballot-scanning dst_idx.
+// Two shapes of the same arithmetic:
+//   * rows of at most 2*64 lane-chunks (C <= 1024 bf16 / 512 fp32 with 16-byte lanes): the sources of one
+//     64-rank block are compacted onto lanes 0..nsrc-1 (ds_permute), their tokens and sizes fetched as ONE
+//     vector load each, and their row chunks fetched four sources at a time before the sequential adds --
+//     a destination with k sources costs ~2 + k/4 dependent memory round trips instead of ~2k;
+//   * anything wider: the plain sequential loop.
+template <typename TX, typename TS, int VEC, int OP>
+__device__ __forceinline__ void merge_dst_row(const TX *__restrict__ xg, const TS *__restrict__ sg, int C,
+                                              int64_t tstride, int r, int g, int j,
+                                              const int64_t *__restrict__ srcg,
+                                              const int64_t *__restrict__ dstg, const uint8_t *__restrict__ keep,
+                                              TX *__restrict__ orow, TS *__restrict__ srow, int lane) {
+    const int t = 2 * j + 1;
+    const TX *xr = xg + (int64_t)t * tstride;
+    float s_own = 1.0f;
+    if (OP == OP_WAVG) s_own = sg ? to_f32(sg[t]) : 1.0f;
+    const bool narrow_row = C <= 2 * WAVE * VEC;
+    constexpr int NB = VEC >= 8 ? 2 : 4;  // source rows fetched together (register budget)
+
+    if (narrow_row) {
+        const int c0 = lane * VEC, c1 = (WAVE + lane) * VEC;
+        const bool a0 = c0 < C, a1 = c1 < C;
+        float acc0[VEC], acc1[VEC];
+        if (a0) load_pack<TX, VEC>(xr + c0, acc0);
+        if (a1) load_pack<TX, VEC>(xr + c1, acc1);
+        // hybrid: does any incoming edge fall below the threshold (merge.py:326)?
+        bool kill = false;
+        if (keep && OP != OP_DROP) {
+            for (int base = 0; base < r; base += WAVE) {
+                const int k = base + lane;
+                const bool m = (k < r) && ((int)dstg[k] == j);
+                kill = kill || (__ballot(m && keep[(int64_t)g * r + k] == 0) != 0ull);
+            }
+        }
+        float ssum = s_own;
+        int cnt = 1;
+        if (OP == OP_WAVG) {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                if (a0) acc0[e] = __fmul_rn(acc0[e], s_own);
+                if (a1) acc1[e] = __fmul_rn(acc1[e], s_own);
+            }
+        }
+        if (kill) {
+            if (OP == OP_WAVG) ssum = __fmul_rn(ssum, 0.0f);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                if (a0) acc0[e] = __fmul_rn(acc0[e], 0.0f);
+                if (a1) acc1[e] = __fmul_rn(acc1[e], 0.0f);
+            }
+        }
+        if (OP != OP_DROP) {
+            for (int base = 0; base < r; base += WAVE) {
+                const int k = base + lane;
+                const bool m = (k < r) && ((int)dstg[k] == j);
+                const unsigned long long mk = __ballot(m);
+                if (mk == 0ull) continue;
+                const int nsrc = __popcll(mk);
+                // lane L < nsrc learns the lane (= rank offset) of the L-th source of this block
+                const int myrank = __popcll(mk & ((1ull << lane) - 1ull));
+                const int kL = __builtin_amdgcn_ds_permute(m ? myrank * 4 : 63 * 4 + 256, m ? lane : 0);
+                int tsL = 0;
+                float sL = 1.0f;
+                if (lane < nsrc) {
+                    tsL = 2 * (int)srcg[base + kL];
+                    if (OP == OP_WAVG && sg) sL = to_f32(sg[tsL]);
+                }
+                for (int e0 = 0; e0 < nsrc; e0 += NB) {
+                    typedef Pack<TX, VEC> __attribute__((aligned(sizeof(TX) * VEC))) PK;
+                    PK p0[NB], p1[NB];  // raw chunks of up to NB source rows, all in flight together
+                    float sq[NB];
+#pragma unroll
+                    for (int u = 0; u < NB; ++u) {
+                        const int e = (e0 + u < nsrc) ? e0 + u : nsrc - 1;
+                        const int tsu = __builtin_amdgcn_readlane(tsL, e);
+                        sq[u] = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(sL), e));
+                        const TX *sr = xg + (int64_t)tsu * tstride;
+                        if (a0) p0[u] = *reinterpret_cast<const PK *>(sr + c0);
+                        if (a1) p1[u] = *reinterpret_cast<const PK *>(sr + c1);
+                    }
+#pragma unroll
+                    for (int u = 0; u < NB; ++u) {
+                        if (e0 + u < nsrc) {
+#pragma unroll
+                            for (int e = 0; e < VEC; ++e) {
+                                if (a0) {
+                                    const float v = to_f32(p0[u].e[e]);
+                                    acc0[e] = reduce_step<OP>(acc0[e], (OP == OP_WAVG) ? __fmul_rn(v, sq[u]) : v);
+                                }
+                                if (a1) {
+                                    const float v = to_f32(p1[u].e[e]);
+                                    acc1[e] = reduce_step<OP>(acc1[e], (OP == OP_WAVG) ? __fmul_rn(v, sq[u]) : v);
+                                }
+                            }
+                            if (OP == OP_WAVG) ssum = __fadd_rn(ssum, sq[u]);
+                            ++cnt;
+                        }
+                    }
+                }
+            }
+        }
+        if (OP == OP_WAVG) {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                if (a0) acc0[e] = __fdiv_rn(acc0[e], ssum);
+                if (a1) acc1[e] = __fdiv_rn(acc1[e], ssum);
+            }
+        } else if (OP == TOME_MEAN && cnt > 1) {
+            const float fc = (float)cnt;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                if (a0) acc0[e] = __fdiv_rn(acc0[e], fc);
+                if (a1) acc1[e] = __fdiv_rn(acc1[e], fc);
+            }
+        }
+        if (a0) store_pack<TX, VEC>(orow + c0, acc0);
+        if (a1) store_pack<TX, VEC>(orow + c1, acc1);
+        if (OP == OP_WAVG && lane == 0) *srow = from_f32<TS>(ssum);
+        return;
+    }
+
+    // wide rows: sequential form
+    unsigned long long mask0 = 0ull;
+    bool kill = false;
+    if (OP != OP_DROP) {
+        for (int base = 0; base < r; base += WAVE) {
+            const int k = base + lane;
+            const bool m = (k < r) && ((int)dstg[k] == j);
+            const unsigned long long mk = __ballot(m);
+            if (base == 0) mask0 = mk;
+            if (keep) kill = kill || (__ballot(m && keep[(int64_t)g * r + k] == 0) != 0ull);
+        }
+    }
+    float ssum = s_own;
+    int cnt = 1;
+    if (OP == OP_WAVG) {
+        if (kill) ssum = __fmul_rn(ssum, 0.0f);
+    }
+    bool first_chunk = true;
+    for (int c0 = 0; c0 < C; c0 += WAVE * VEC) {
+        const int c = c0 + lane * VEC;
+        const bool act = c < C;
+        float acc[VEC];
+        if (act) {
+            load_pack<TX, VEC>(xr + c, acc);
+            if (OP == OP_WAVG) {
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) acc[e] = __fmul_rn(acc[e], s_own);
+            }
+            if (kill) {
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) acc[e] = __fmul_rn(acc[e], 0.0f);
+            }
+        }
+        if (OP != OP_DROP) {
+            for (int base = 0; base < r; base += WAVE) {
+                unsigned long long mk;
+                if (base == 0) mk = mask0;
+                else {
+                    const int k = base + lane;
+                    mk = __ballot((k < r) && ((int)dstg[k] == j));
+                }
+                while (mk) {
+                    const int b = __ffsll((long long)mk) - 1;
+                    mk &= mk - 1ull;
+                    const int ts = 2 * (int)srcg[base + b];
+                    float s2 = 1.0f;
+                    if (OP == OP_WAVG) s2 = sg ? to_f32(sg[ts]) : 1.0f;
+                    if (act) {
+                        float v[VEC];
+                        load_pack<TX, VEC>(xg + (int64_t)ts * tstride + c, v);
+#pragma unroll
+                        for (int e = 0; e < VEC; ++e) {
+                            float p = (OP == OP_WAVG) ? __fmul_rn(v[e], s2) : v[e];
+                            acc[e] = reduce_step<OP>(acc[e], p);
+                        }
+                    }
+                    if (first_chunk) {
+                        if (OP == OP_WAVG) ssum = __fadd_rn(ssum, s2);
+                        ++cnt;
+                    }
+                }
+            }
+        }
+        first_chunk = false;
+        if (act) {
+            if (OP == OP_WAVG) {
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) acc[e] = __fdiv_rn(acc[e], ssum);
+            } else if (OP == TOME_MEAN) {
+                if (cnt > 1) {
+                    const float fc = (float)cnt;
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) acc[e] = __fdiv_rn(acc[e], fc);
+                }
+            }
+            store_pack<TX, VEC>(orow + c, acc);
+        }
+    }
+    if (OP == OP_WAVG && lane == 0) *srow = from_f32<TS>(ssum);
+}
+
+// inverse of the output layout (merge.py:82-85): output row o -> (is it a B/dst row?, index in its set)
+__device__ __forceinline__ void decode_out_row(int o, int U, int distill, bool &is_dst, int &idx) {
+    if (!distill) {
+        is_dst = o >= U;
+        idx = is_dst ? o - U : o;
+    } else if (o == 0) { is_dst = false; idx = 0; }
+    else if (o == 1) { is_dst = true; idx = 0; }
+    else if (o <= U) { is_dst = false; idx = o - 1; }
+    else { is_dst = true; idx = o - U; }
+}
+
+// Generic form: one wave per output row, any C / alignment / r.  (The hot shapes go through
+// k_merge_rows_fast below; this one serves odd channel counts such as the size column or source matrices.)
+template <typename TX, typename TS, int VEC, int OP>
+__global__ __launch_bounds__(256) void k_merge_rows(const TX *__restrict__ x, const TS *__restrict__ size,
+                                                    int n, int T_, int C, int r,
+                                                    const int64_t *__restrict__ src_idx,
+                                                    const int64_t *__restrict__ dst_idx,
+                                                    const int64_t *__restrict__ unm_idx, int distill,
+                                                    const uint8_t *__restrict__ keep, TX *__restrict__ xout,
+                                                    TS *__restrict__ sout, TokLayout lin, TokLayout lout) {
+    const int lane = threadIdx.x & 63;
+    const int To = T_ - r;
+    const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= (int64_t)n * To) return;
+    const int g = (int)(row / To);
+    const int o = (int)(row - (int64_t)g * To);
+    const int T1 = (T_ + 1) >> 1, U = T1 - r;
+    bool is_dst;
+    int idx;
+    decode_out_row(o, U, distill, is_dst, idx);
+
+    const TX *xg = group_ptr(x, lin, g);
+    const TS *sg = size ? size + (int64_t)g * T_ : nullptr;
+    TX *orow = group_ptr(xout, lout, g) + (int64_t)o * lout.tok_stride;
+    if (!is_dst) {
+        const int t = 2 * (int)unm_idx[(int64_t)g * U + idx];
+        const TX *xr = xg + (int64_t)t * lin.tok_stride;
+        float s = 1.0f;
+        if (OP == OP_WAVG) s = sg ? to_f32(sg[t]) : 1.0f;
+        for (int c = lane * VEC; c < C; c += WAVE * VEC) {
+            float v[VEC];
+            load_pack<TX, VEC>(xr + c, v);
+            if (OP == OP_WAVG) {
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) v[e] = __fdiv_rn(__fmul_rn(v[e], s), s);
+            }
+            store_pack<TX, VEC>(orow + c, v);
+        }
+        if (OP == OP_WAVG && lane == 0) sout[row] = from_f32<TS>(s);
+        return;
+    }
+    merge_dst_row<TX, TS, VEC, OP>(xg, sg, C, lin.tok_stride, r, g, idx, src_idx ? src_idx + (int64_t)g * r : nullptr,
+                                   dst_idx ? dst_idx + (int64_t)g * r : nullptr, keep, orow,
+                                   sout ? sout + row : nullptr, lane);
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_merge_rows_fast: the HBM-bound form for rows made of whole 16-byte chunks (C*sizeof(TX) % 16 == 0,
+// at most 384 chunks per R rows).  A wave owns R consecutive OUTPUT rows of one group, flattens their
+// R*cpr 16-byte chunks over its lanes (6 chunks per lane, every lane busy, stores contiguous across the
+// R rows) and issues all of its loads before touching any of them, so ~6 KiB per wave are in flight.
+// Rows that nothing merges into are moved as raw bits when their size is 1 ((x*1)/1 == x bit for bit)
+// or scaled in fp32 otherwise; the few rows that receive sources are finished by merge_dst_row.
+// ------------------------------------------------------------------------------------------------
+#define FAST_NIT 6
+#define FAST_MAXR 4
+
+template <typename TX, typename TS, int OP, int NIT>
+__global__ __launch_bounds__(256) void k_merge_rows_fast(const TX *__restrict__ x, const TS *__restrict__ size,
+                                                         int n, int T_, int C, int r, int R, int cpr,
+                                                         const int64_t *__restrict__ src_idx,
+                                                         const int64_t *__restrict__ dst_idx,
+                                                         const int64_t *__restrict__ unm_idx, int distill,
+                                                         const uint8_t *__restrict__ keep, TX *__restrict__ xout,
+                                                         TS *__restrict__ sout, TokLayout lin, TokLayout lout,
+                                                         int cls_rows) {
+    constexpr int VEC = 16 / sizeof(TX);
+    const int lane = threadIdx.x & 63;
+    const int To = T_ - r;
+    const int rg_per_group = (To + R - 1) / R;
+    const int64_t w = (int64_t)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t n_main = (int64_t)n * rg_per_group;
+    const int64_t n_edge = (OP == OP_DROP) ? 0 : (int64_t)n * r;
+    if (w >= n_main + n_edge) {
+        // the class tokens kept aside by the regrouped callers (timesformer.py:89,107): plain row copies
+        const int64_t b = w - n_main - n_edge;
+        if (b < cls_rows) {
+            const uint4 *src = reinterpret_cast<const uint4 *>(x + b * lin.outer_stride);
+            uint4 *dst = reinterpret_cast<uint4 *>(xout + b * lout.outer_stride);
+            for (int c = lane; c < cpr; c += WAVE) dst[c] = src[c];
+        }
+        return;
+    }
+    if (w >= n_main) {
+        // edge waves: one per (group, rank k).  The wave of the FIRST edge into a destination builds that
+        // row (all its sources, rank order); the others leave.  Destinations with sources therefore never
+        // hold up the streaming waves above, and run concurrently with them.
+        const int64_t ew = w - n_main;
+        const int g = (int)(ew / r);
+        const int k = (int)(ew - (int64_t)g * r);
+        const int64_t *dstg = dst_idx + (int64_t)g * r;
+        const int j = (int)dstg[k];
+        bool earlier = false;
+        for (int base = 0; base < k; base += WAVE) {
+            const int kk = base + lane;
+            earlier = earlier || (__ballot((kk < k) && ((int)dstg[kk] == j)) != 0ull);
+        }
+        if (earlier) return;
+        const int T1e = (T_ + 1) >> 1, Ue = T1e - r;
+        const int o = out_row_dst(j, Ue, distill);
+        merge_dst_row<TX, TS, VEC, OP>(group_ptr(x, lin, g), size ? size + (int64_t)g * T_ : nullptr, C, lin.tok_stride,
+                                       r, g, j, src_idx + (int64_t)g * r, dstg, keep,
+                                       group_ptr(xout, lout, g) + (int64_t)o * lout.tok_stride,
+                                       sout ? sout + (int64_t)g * To + o : nullptr, lane);
+        return;
+    }
+    const int g = (int)(w / rg_per_group);
+    const int o0 = (int)(w - (int64_t)g * rg_per_group) * R;
+    const int T1 = (T_ + 1) >> 1, U = T1 - r;
+    const TX *xg = group_ptr(x, lin, g);
+    TX *og = group_ptr(xout, lout, g);
+    const TS *sg = size ? size + (int64_t)g * T_ : nullptr;
+    const int64_t *dstg = dst_idx ? dst_idx + (int64_t)g * r : nullptr;
+
+    // per-row facts, computed by lanes 0..R-1 in parallel and broadcast as wave-uniform scalars: source
+    // token, B-row number, "something merges into it", size.  Load order matters for latency: the first block
+    // of dst_idx and the unm_idx entries go out together; the sizes are requested as soon as the tokens are
+    // known but only READ after the token rows' own loads have been issued, so a wave waits for two memory
+    // round trips (index -> rows), not three.
+    const int d_first = (OP != OP_DROP && lane < r) ? (int)dstg[lane] : -2;
+    int my_tok = 0, my_j = -1;
+    float my_s = 1.0f;
+    bool my_valid = false;
+    if (lane < R) {
+        const int o = o0 + lane;
+        if (o < To) {
+            my_valid = true;
+            bool is_dst;
+            int idx;
+            decode_out_row(o, U, distill, is_dst, idx);
+            if (is_dst) {
+                my_tok = 2 * idx + 1;
+                my_j = idx;
+            } else {
+                my_tok = 2 * (int)unm_idx[(int64_t)g * U + idx];
+            }
+        }
+    }
+    TS my_s_raw;
+    const bool load_size = (OP == OP_WAVG) && sg && my_valid;
+    if (load_size) my_s_raw = sg[my_tok];
+    const unsigned long long vmask = __ballot(my_valid);
+    const int tok0 = __builtin_amdgcn_readlane(my_tok, 0), tok1 = __builtin_amdgcn_readlane(my_tok, 1),
+              tok2 = __builtin_amdgcn_readlane(my_tok, 2), tok3 = __builtin_amdgcn_readlane(my_tok, 3);
+    const int j0 = __builtin_amdgcn_readlane(my_j, 0), j1 = __builtin_amdgcn_readlane(my_j, 1),
+              j2 = __builtin_amdgcn_readlane(my_j, 2), j3 = __builtin_amdgcn_readlane(my_j, 3);
+    bool e0 = false, e1 = false, e2 = false, e3 = false;  // rows that receive sources
+    if (OP != OP_DROP) {
+        e0 = __ballot(d_first == j0) != 0ull;
+        e1 = __ballot(d_first == j1) != 0ull;
+        e2 = __ballot(d_first == j2) != 0ull;
+        e3 = __ballot(d_first == j3) != 0ull;
+        for (int base = WAVE; base < r; base += WAVE) {
+            const int k = base + lane;
+            const int d = (k < r) ? (int)dstg[k] : -2;
+            e0 = e0 || (__ballot(d == j0) != 0ull);
+            e1 = e1 || (__ballot(d == j1) != 0ull);
+            e2 = e2 || (__ballot(d == j2) != 0ull);
+            e3 = e3 || (__ballot(d == j3) != 0ull);
+        }
+    }
+    const bool ok0 = (vmask & 1ull) && !e0, ok1 = (vmask & 2ull) && !e1, ok2 = (vmask & 4ull) && !e2,
+               ok3 = (vmask & 8ull) && !e3;
+
+    // flattened chunk loop: chunk q of the R-row slab -> (row q / cpr, 16-byte column q % cpr)
+    const int total = R * cpr;
+    uint4 raw[NIT];
+    int rowof[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int q = it * WAVE + lane;
+        const int rr = (q >= cpr) + (q >= 2 * cpr) + (q >= 3 * cpr);
+        const int cc = q - rr * cpr;
+        const int t = rr == 0 ? tok0 : (rr == 1 ? tok1 : (rr == 2 ? tok2 : tok3));
+        const bool ok = (rr == 0 ? ok0 : (rr == 1 ? ok1 : (rr == 2 ? ok2 : ok3))) && (q < total);
+        rowof[it] = ok ? rr : -1;
+        if (ok)
+            raw[it] = *reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(xg + (int64_t)t * lin.tok_stride) +
+                                                       cc * 16);
+    }
+    if (load_size) my_s = to_f32(my_s_raw);
+    const float sz0 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(my_s), 0)),
+                sz1 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(my_s), 1)),
+                sz2 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(my_s), 2)),
+                sz3 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(my_s), 3));
+    // (x*s)/s is x itself when s is 1, and also when s is a power of two and x came from a 16-bit
+    // format (the fp32 product cannot overflow): those rows move as raw bits
+    constexpr bool narrow = sizeof(TX) == 2;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int rr = rowof[it];
+        if (rr < 0) continue;
+        const int q = it * WAVE + lane;
+        const float s = rr == 0 ? sz0 : (rr == 1 ? sz1 : (rr == 2 ? sz2 : sz3));
+        uint4 outv = raw[it];
+        if (OP == OP_WAVG) {
+            const uint32_t sb = __float_as_uint(s);
+            const bool exact = (s == 1.0f) || (narrow && (sb & 0x007FFFFFu) == 0u && s >= 1.0f && s <= 65536.0f);
+            if (!exact) {
+                Pack<TX, VEC> pk;
+                __builtin_memcpy(&pk, &raw[it], 16);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) pk.e[e] = from_f32<TX>(__fdiv_rn(__fmul_rn(to_f32(pk.e[e]), s), s));
+                __builtin_memcpy(&outv, &pk, 16);
+            }
+        }
+        const int cc = q - rr * cpr;
+        *reinterpret_cast<uint4 *>(reinterpret_cast<char *>(og + (int64_t)(o0 + rr) * lout.tok_stride) + cc * 16) = outv;
+    }
+    if (OP == OP_WAVG && lane < R && my_valid) {
+        const bool mine_has_edges = lane == 0 ? e0 : (lane == 1 ? e1 : (lane == 2 ? e2 : e3));
+        if (!mine_has_edges) sout[(int64_t)g * To + o0 + lane] = from_f32<TS>(my_s);
+    }
+}
+
+// k_unmerge_rows: merge.py:87-100 as a scatter from the merged sequence: one wave per INPUT row; a
+// destination row also lands on every even slot that was merged into it.  src and unm partition the
+// even slots, so every output row is written exactly once and no zero fill is needed.
+template <typename TX, int VEC>
+__global__ __launch_bounds__(256) void k_unmerge_rows(const TX *__restrict__ x, int n, int T_, int C, int r,
+                                                      const int64_t *__restrict__ src_idx,
+                                                      const int64_t *__restrict__ dst_idx,
+                                                      const int64_t *__restrict__ unm_idx,
+                                                      TX *__restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int To = T_ - r;
+    const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= (int64_t)n * To) return;
+    const int g = (int)(row / To);
+    const int o = (int)(row - (int64_t)g * To);
+    const int T1 = (T_ + 1) >> 1, U = T1 - r;
+    const TX *xr = x + row * C;
+    TX *og = out + (int64_t)g * T_ * C;
+    if (o < U) {
+        TX *dst = og + (int64_t)(2 * (int)unm_idx[(int64_t)g * U + o]) * C;
+        for (int c = lane * VEC; c < C; c += WAVE * VEC) {
+            float v[VEC];
+            load_pack<TX, VEC>(xr + c, v);
+            store_pack<TX, VEC>(dst + c, v);
+        }
+        return;
+    }
+    const int j = o - U;
+    const int64_t *srcg = src_idx + (int64_t)g * r, *dstg = dst_idx + (int64_t)g * r;
+    for (int c = lane * VEC; c < C; c += WAVE * VEC) {
+        float v[VEC];
+        load_pack<TX, VEC>(xr + c, v);
+        store_pack<TX, VEC>(og + (int64_t)(2 * j + 1) * C + c, v);
+    }
+    for (int base = 0; base < r; base += WAVE) {
+        const int k = base + lane;
+        unsigned long long mk = __ballot((k < r) && ((int)dstg[k] == j));
+        while (mk) {
+            const int b = __ffsll((long long)mk) - 1;
+            mk &= mk - 1ull;
+            TX *dst = og + (int64_t)(2 * (int)srcg[base + b]) * C;
+            for (int c = lane * VEC; c < C; c += WAVE * VEC) {
+                float v[VEC];
+                load_pack<TX, VEC>(xr + c, v);
+                store_pack<TX, VEC>(dst + c, v);
+            }
+        }
+    }
+}
+
