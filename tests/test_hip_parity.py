@@ -485,3 +485,25 @@ def test_unused_variants_shapes():
     assert unmerge(merge(x)).shape == x.shape
     with pytest.raises(TomeHipError):
         tm.kth_bipartite_soft_matching(torch.randn(1, 8, 4), 2)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.bfloat16, 2 ** -7), (torch.float16, 2 ** -10)])
+@pytest.mark.parametrize("n,T,C,r,cls", [(3, 197, 768, 16, True), (2, 64, 64, 30, False), (4, 392, 1024, 150, False)])
+def test_merge_wavg_ln_fused(n, T, C, r, cls, dtype, tol):
+    """tome_merge_wavg_ln: x_out bit-identical to tome_merge_wavg, y_out = LayerNorm(x_out) within one unit of
+    the format's epsilon of an fp32 LayerNorm of the same stored tokens (the block's norm2)."""
+    from tome import _abi
+    tm = _tome()
+    seed = 31 * n + T + C
+    metric = dev(synth.normal_like((n, T, 64), seed))
+    x = dev(synth.normal_like((n, T, C), seed + 1), dtype)
+    size = dev(synth.small_ints((n, T, 1), seed + 2, 1, 4), dtype)
+    w = dev(1.0 + 0.1 * synth.normal_like((C,), seed + 3), dtype)
+    b = dev(0.1 * synth.normal_like((C,), seed + 4), dtype)
+    merge, _ = tm.bipartite_soft_matching(metric, r, cls)
+    want_x, want_s = tm.merge_wavg(merge, x, size)
+    got_x, got_y, got_s = _abi.merge_wavg_ln(merge.plan, x, size, w, b, 1e-6)
+    assert torch.equal(got_x, want_x) and torch.equal(got_s, want_s)
+    ref = torch.nn.functional.layer_norm(want_x.float(), (C,), w.float(), b.float(), 1e-6)
+    err = (got_y.float() - ref).abs()
+    assert float((err / ref.abs().clamp(min=1.0)).max()) <= tol, float(err.max())

@@ -357,37 +357,48 @@ template <typename TX, typename TS, int OP>
 static int launch_merge_rows(const void *x, const void *size, int64_t n, int64_t T, int64_t C, int64_t r,
                              const int64_t *src, const int64_t *dst, const int64_t *unm, int distill,
                              const uint8_t *keep, void *xout, void *sout, hipStream_t st,
-                             const TokLayout *lin_p = nullptr, const TokLayout *lout_p = nullptr, int cls_rows = 0) {
+                             const TokLayout *lin_p = nullptr, const TokLayout *lout_p = nullptr, int cls_rows = 0,
+                             const LnArgs *ln_p = nullptr) {
     constexpr int VEC = 16 / sizeof(TX);
     const int64_t To = T - r;
     const TokLayout lin = lin_p ? *lin_p : contiguous_layout(T, C);
     const TokLayout lout = lout_p ? *lout_p : contiguous_layout(To, C);
     const bool vec_ok = (C % VEC == 0) && aligned16(x) && aligned16(xout);
     const int64_t cpr = C / VEC;  // 16-byte chunks per row
+    const LnArgs no_ln{nullptr, nullptr, nullptr, 0.0f};
     if (vec_ok && cpr <= FAST_NIT * WAVE) {
-        // rows per wave: measured on MI355X, a plain 16-byte copy runs fastest with ONE load per lane in
-        // flight and many waves (6.0-6.9 TB/s) and loses ~10 % at four; NIT=3 (two 1536-byte rows per wave)
-        // is the smallest slab that still keeps every lane busy for 768-channel bf16 tokens
+        // rows per wave: measured on MI355X, NIT=6 (four 1536-byte rows per wave for 768-channel bf16 tokens)
+        // beats NIT=3 by ~4 %; TOME_MERGE_NIT=3 keeps the other variant reachable for re-measurement
         static const int nit_pref = [] {
             const char *e = getenv("TOME_MERGE_NIT");
             int v = e ? atoi(e) : 0;
             return (v == 3 || v == 6) ? v : 6;
         }();
-        const int nit = (cpr <= 3 * WAVE) ? nit_pref : FAST_NIT;
+        const int nit = (cpr <= 3 * WAVE && !ln_p) ? nit_pref : FAST_NIT;
         int R = (int)((nit * WAVE) / cpr);
         if (R > FAST_MAXR) R = FAST_MAXR;
         const int64_t waves = n * ((To + R - 1) / R) + (OP == OP_DROP ? 0 : n * r) + cls_rows;
-        if (nit == 3)
-            hipLaunchKernelGGL((k_merge_rows_fast<TX, TS, OP, 3>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st,
-                               (const TX *)x, (const TS *)size, (int)n, (int)T, (int)C, (int)r, R, (int)cpr, src, dst,
-                               unm, distill, keep, (TX *)xout, (TS *)sout, lin, lout, cls_rows);
+        const dim3 grid((unsigned)((waves + 3) / 4));
+        if (ln_p) {
+            if (OP != OP_WAVG || sizeof(TX) != 2 || cpr > 2 * WAVE || !aligned16(ln_p->y) || !aligned16(ln_p->weight) ||
+                !aligned16(ln_p->bias))
+                return fail(TOME_EINVAL, "fused LayerNorm needs 16-bit tokens with C <= 1024 and 16-byte aligned buffers");
+            if constexpr (OP == OP_WAVG && sizeof(TX) == 2)
+                hipLaunchKernelGGL((k_merge_rows_fast<TX, TS, OP, 6, true>), grid, dim3(256), 0, st, (const TX *)x,
+                                   (const TS *)size, (int)n, (int)T, (int)C, (int)r, R, (int)cpr, src, dst, unm, distill,
+                                   keep, (TX *)xout, (TS *)sout, lin, lout, cls_rows, *ln_p);
+        } else if (nit == 3)
+            hipLaunchKernelGGL((k_merge_rows_fast<TX, TS, OP, 3>), grid, dim3(256), 0, st, (const TX *)x,
+                               (const TS *)size, (int)n, (int)T, (int)C, (int)r, R, (int)cpr, src, dst, unm, distill,
+                               keep, (TX *)xout, (TS *)sout, lin, lout, cls_rows, no_ln);
         else
-            hipLaunchKernelGGL((k_merge_rows_fast<TX, TS, OP, 6>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st,
-                               (const TX *)x, (const TS *)size, (int)n, (int)T, (int)C, (int)r, R, (int)cpr, src, dst,
-                               unm, distill, keep, (TX *)xout, (TS *)sout, lin, lout, cls_rows);
+            hipLaunchKernelGGL((k_merge_rows_fast<TX, TS, OP, 6>), grid, dim3(256), 0, st, (const TX *)x,
+                               (const TS *)size, (int)n, (int)T, (int)C, (int)r, R, (int)cpr, src, dst, unm, distill,
+                               keep, (TX *)xout, (TS *)sout, lin, lout, cls_rows, no_ln);
         return check_launch("k_merge_rows_fast");
     }
-    if (cls_rows) return fail(TOME_EINVAL, "regrouped merge needs rows of whole 16-byte chunks (C=%lld)", (long long)C);
+    if (cls_rows || ln_p)
+        return fail(TOME_EINVAL, "regrouped / LayerNorm-fused merge needs rows of whole 16-byte chunks (C=%lld)", (long long)C);
     const int64_t rows = n * To;
     const unsigned nb = (unsigned)((rows + 3) / 4);
     if (vec_ok)
@@ -427,6 +438,27 @@ extern "C" int tome_merge_wavg(const void *x, int x_dtype, const void *size, int
     if (x_dtype == TOME_F16 && size_dtype == TOME_F32) WAVG(f16_t, float);
 #undef WAVG
     return fail(TOME_EINVAL, "tome_merge_wavg: unsupported dtypes x=%d size=%d", x_dtype, size_dtype);
+}
+
+extern "C" int tome_merge_wavg_ln(const void *x, int x_dtype, const void *size, int size_dtype, int64_t n, int64_t T,
+                                  int64_t C, int64_t r, const int64_t *src_idx, const int64_t *dst_idx,
+                                  const int64_t *unm_idx, int distill_token, const uint8_t *edge_keep,
+                                  const void *ln_weight, const void *ln_bias, float eps, void *x_out, void *y_out,
+                                  void *size_out, tome_stream_t stream) {
+    if (int rc = check_merge_args("tome_merge_wavg_ln", x, n, T, C, r, x_out)) return rc;
+    if (!src_idx || !dst_idx || (!unm_idx && (T + 1) / 2 > r) || !size_out || !y_out || !ln_weight || !ln_bias)
+        return fail(TOME_EINVAL, "tome_merge_wavg_ln: null buffer");
+    const LnArgs ln{ln_weight, ln_bias, y_out, eps};
+    hipStream_t st = (hipStream_t)stream;
+#define WAVGLN(TX, TS)                                                                                         \
+    return launch_merge_rows<TX, TS, OP_WAVG>(x, size, n, T, C, r, src_idx, dst_idx, unm_idx, distill_token,   \
+                                              edge_keep, x_out, size_out, st, nullptr, nullptr, 0, &ln)
+    if (x_dtype == TOME_BF16 && size_dtype == TOME_BF16) WAVGLN(bf16_t, bf16_t);
+    if (x_dtype == TOME_BF16 && size_dtype == TOME_F32) WAVGLN(bf16_t, float);
+    if (x_dtype == TOME_F16 && size_dtype == TOME_F16) WAVGLN(f16_t, f16_t);
+    if (x_dtype == TOME_F16 && size_dtype == TOME_F32) WAVGLN(f16_t, float);
+#undef WAVGLN
+    return fail(TOME_EINVAL, "tome_merge_wavg_ln: 16-bit tokens only (x=%d size=%d)", x_dtype, size_dtype);
 }
 
 extern "C" int tome_merge_wavg_regrouped(const void *x, int x_dtype, const void *size, int size_dtype, int64_t B,

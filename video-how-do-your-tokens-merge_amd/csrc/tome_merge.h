@@ -27,6 +27,21 @@ template <typename TX> __device__ __forceinline__ TX *group_ptr(TX *p, const Tok
     return p + L.base + (int64_t)(g / L.inner) * L.outer_stride + (int64_t)(g % L.inner) * L.inner_stride;
 }
 
+// Optional LayerNorm fused behind the merge (the block's norm2 -- tome/patch/videomae.py:27 `self.norm2(x)`,
+// vivit.py:41 `layernorm_after`): y = (x' - mean) * rstd * weight + bias over the channels of every merged
+// row, fp32 statistics (two passes over the registers: mean, then centred variance), written next to x'.
+struct LnArgs {
+    const void *weight, *bias;  // [C] of the token dtype
+    void *y;                    // [n, T-r, C] of the token dtype, same row layout as x_out
+    float eps;
+};
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
 // One destination row (odd token 2j+1 plus every source merged into it), whole wave, contract order:
 // own term first, then the sources in src_idx (rank) order found by ballot-scanning dst_idx.
 // Two shapes of the same arithmetic:
@@ -35,12 +50,13 @@ template <typename TX> __device__ __forceinline__ TX *group_ptr(TX *p, const Tok
 //     vector load each, and their row chunks fetched four sources at a time before the sequential adds --
 //     a destination with k sources costs ~2 + k/4 dependent memory round trips instead of ~2k;
 //   * anything wider: the plain sequential loop.
-template <typename TX, typename TS, int VEC, int OP>
+template <typename TX, typename TS, int VEC, int OP, bool LN = false>
 __device__ __forceinline__ void merge_dst_row(const TX *__restrict__ xg, const TS *__restrict__ sg, int C,
                                               int64_t tstride, int r, int g, int j,
                                               const int64_t *__restrict__ srcg,
                                               const int64_t *__restrict__ dstg, const uint8_t *__restrict__ keep,
-                                              TX *__restrict__ orow, TS *__restrict__ srow, int lane) {
+                                              TX *__restrict__ orow, TS *__restrict__ srow, int lane,
+                                              const LnArgs *ln = nullptr, TX *__restrict__ yrow = nullptr) {
     const int t = 2 * j + 1;
     const TX *xr = xg + (int64_t)t * tstride;
     float s_own = 1.0f;
@@ -147,6 +163,41 @@ __device__ __forceinline__ void merge_dst_row(const TX *__restrict__ xg, const T
         if (a0) store_pack<TX, VEC>(orow + c0, acc0);
         if (a1) store_pack<TX, VEC>(orow + c1, acc1);
         if (OP == OP_WAVG && lane == 0) *srow = from_f32<TS>(ssum);
+        if (LN) {
+            // LayerNorm of the row as stored (rounded to the token dtype), the whole row is in this wave
+            float part = 0.0f;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                acc0[e] = a0 ? to_f32(from_f32<TX>(acc0[e])) : 0.0f;
+                acc1[e] = a1 ? to_f32(from_f32<TX>(acc1[e])) : 0.0f;
+                part += acc0[e] + acc1[e];
+            }
+            const float mean = wave_sum(part) / (float)C;
+            part = 0.0f;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                const float d0 = a0 ? acc0[e] - mean : 0.0f, d1 = a1 ? acc1[e] - mean : 0.0f;
+                part += d0 * d0 + d1 * d1;
+            }
+            const float rstd = 1.0f / __builtin_sqrtf(wave_sum(part) / (float)C + ln->eps);
+            const TX *lw = reinterpret_cast<const TX *>(ln->weight), *lb = reinterpret_cast<const TX *>(ln->bias);
+            if (a0) {
+                float w8[VEC], b8[VEC];
+                load_pack<TX, VEC>(lw + c0, w8);
+                load_pack<TX, VEC>(lb + c0, b8);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) acc0[e] = (acc0[e] - mean) * rstd * w8[e] + b8[e];
+                store_pack<TX, VEC>(yrow + c0, acc0);
+            }
+            if (a1) {
+                float w8[VEC], b8[VEC];
+                load_pack<TX, VEC>(lw + c1, w8);
+                load_pack<TX, VEC>(lb + c1, b8);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) acc1[e] = (acc1[e] - mean) * rstd * w8[e] + b8[e];
+                store_pack<TX, VEC>(yrow + c1, acc1);
+            }
+        }
         return;
     }
 
@@ -299,7 +350,7 @@ __global__ __launch_bounds__(256) void k_merge_rows(const TX *__restrict__ x, co
 #define FAST_NIT 6
 #define FAST_MAXR 4
 
-template <typename TX, typename TS, int OP, int NIT>
+template <typename TX, typename TS, int OP, int NIT, bool LN = false>
 __global__ __launch_bounds__(256) void k_merge_rows_fast(const TX *__restrict__ x, const TS *__restrict__ size,
                                                          int n, int T_, int C, int r, int R, int cpr,
                                                          const int64_t *__restrict__ src_idx,
@@ -307,7 +358,7 @@ __global__ __launch_bounds__(256) void k_merge_rows_fast(const TX *__restrict__ 
                                                          const int64_t *__restrict__ unm_idx, int distill,
                                                          const uint8_t *__restrict__ keep, TX *__restrict__ xout,
                                                          TS *__restrict__ sout, TokLayout lin, TokLayout lout,
-                                                         int cls_rows) {
+                                                         int cls_rows, LnArgs ln) {
     constexpr int VEC = 16 / sizeof(TX);
     const int lane = threadIdx.x & 63;
     const int To = T_ - r;
@@ -342,10 +393,11 @@ __global__ __launch_bounds__(256) void k_merge_rows_fast(const TX *__restrict__ 
         if (earlier) return;
         const int T1e = (T_ + 1) >> 1, Ue = T1e - r;
         const int o = out_row_dst(j, Ue, distill);
-        merge_dst_row<TX, TS, VEC, OP>(group_ptr(x, lin, g), size ? size + (int64_t)g * T_ : nullptr, C, lin.tok_stride,
-                                       r, g, j, src_idx + (int64_t)g * r, dstg, keep,
-                                       group_ptr(xout, lout, g) + (int64_t)o * lout.tok_stride,
-                                       sout ? sout + (int64_t)g * To + o : nullptr, lane);
+        merge_dst_row<TX, TS, VEC, OP, LN>(
+            group_ptr(x, lin, g), size ? size + (int64_t)g * T_ : nullptr, C, lin.tok_stride, r, g, j,
+            src_idx + (int64_t)g * r, dstg, keep, group_ptr(xout, lout, g) + (int64_t)o * lout.tok_stride,
+            sout ? sout + (int64_t)g * To + o : nullptr, lane, &ln,
+            LN ? group_ptr(reinterpret_cast<TX *>(ln.y), lout, g) + (int64_t)o * lout.tok_stride : nullptr);
         return;
     }
     const int g = (int)(w / rg_per_group);
@@ -450,6 +502,69 @@ __global__ __launch_bounds__(256) void k_merge_rows_fast(const TX *__restrict__ 
         }
         const int cc = q - rr * cpr;
         *reinterpret_cast<uint4 *>(reinterpret_cast<char *>(og + (int64_t)(o0 + rr) * lout.tok_stride) + cc * 16) = outv;
+        if (LN) raw[it] = outv;  // keep the stored bits: LayerNorm runs on exactly what was written
+    }
+    if (LN) {
+        // statistics of the (up to) four rows of this wave: per-lane partials by row, then wave sums
+        float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int rr = rowof[it];
+            Pack<TX, VEC> pk;
+            __builtin_memcpy(&pk, &raw[it], 16);
+            float t = 0.0f;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) t += to_f32(pk.e[e]);
+            s0 += rr == 0 ? t : 0.0f;
+            s1 += rr == 1 ? t : 0.0f;
+            s2 += rr == 2 ? t : 0.0f;
+            s3 += rr == 3 ? t : 0.0f;
+        }
+        const float fc = (float)C;
+        const float m0 = wave_sum(s0) / fc, m1 = wave_sum(s1) / fc, m2 = wave_sum(s2) / fc, m3 = wave_sum(s3) / fc;
+        s0 = s1 = s2 = s3 = 0.0f;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int rr = rowof[it];
+            const float m = rr == 0 ? m0 : (rr == 1 ? m1 : (rr == 2 ? m2 : m3));
+            Pack<TX, VEC> pk;
+            __builtin_memcpy(&pk, &raw[it], 16);
+            float t = 0.0f;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                const float d = to_f32(pk.e[e]) - m;
+                t += d * d;
+            }
+            s0 += rr == 0 ? t : 0.0f;
+            s1 += rr == 1 ? t : 0.0f;
+            s2 += rr == 2 ? t : 0.0f;
+            s3 += rr == 3 ? t : 0.0f;
+        }
+        const float r0 = 1.0f / __builtin_sqrtf(wave_sum(s0) / fc + ln.eps),
+                    r1 = 1.0f / __builtin_sqrtf(wave_sum(s1) / fc + ln.eps),
+                    r2 = 1.0f / __builtin_sqrtf(wave_sum(s2) / fc + ln.eps),
+                    r3 = 1.0f / __builtin_sqrtf(wave_sum(s3) / fc + ln.eps);
+        const TX *lw = reinterpret_cast<const TX *>(ln.weight), *lb = reinterpret_cast<const TX *>(ln.bias);
+        TX *yg = group_ptr(reinterpret_cast<TX *>(ln.y), lout, g);
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int rr = rowof[it];
+            if (rr < 0) continue;
+            const int q = it * WAVE + lane;
+            const int cc = q - rr * cpr;
+            const float m = rr == 0 ? m0 : (rr == 1 ? m1 : (rr == 2 ? m2 : m3));
+            const float rs = rr == 0 ? r0 : (rr == 1 ? r1 : (rr == 2 ? r2 : r3));
+            Pack<TX, VEC> pk;
+            __builtin_memcpy(&pk, &raw[it], 16);
+            float w8[VEC], b8[VEC];
+            load_pack<TX, VEC>(lw + cc * VEC, w8);
+            load_pack<TX, VEC>(lb + cc * VEC, b8);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) pk.e[e] = from_f32<TX>((to_f32(pk.e[e]) - m) * rs * w8[e] + b8[e]);
+            uint4 yv;
+            __builtin_memcpy(&yv, &pk, 16);
+            *reinterpret_cast<uint4 *>(reinterpret_cast<char *>(yg + (int64_t)(o0 + rr) * lout.tok_stride) + cc * 16) = yv;
+        }
     }
     if (OP == OP_WAVG && lane < R && my_valid) {
         const bool mine_has_edges = lane == 0 ? e0 : (lane == 1 ? e1 : (lane == 2 ? e2 : e3));

@@ -17,7 +17,8 @@ LIB_PATH = os.environ.get("TOME_HIP_LIB", os.path.join(_PKG, "lib", "libtome_hip
 SYMBOLS = (
     "tome_abi_version", "tome_last_error", "tome_effective_r", "tome_match_workspace_bytes", "tome_match",
     "tome_match_keys",
-    "tome_match_scores", "tome_edge_keep", "tome_merge_wavg", "tome_merge_wavg_regrouped", "tome_merge", "tome_drop",
+    "tome_match_scores", "tome_edge_keep", "tome_merge_wavg", "tome_merge_wavg_ln", "tome_merge_wavg_regrouped",
+    "tome_merge", "tome_drop",
     "tome_unmerge",
     "tome_profile_enable", "tome_profile_read",
 )
@@ -64,6 +65,9 @@ def lib() -> ctypes.CDLL:
     L.tome_edge_keep.argtypes = [vp, vp, i64, i64, i64, ctypes.c_float, vp, vp]
     L.tome_merge_wavg.restype = i32
     L.tome_merge_wavg.argtypes = [vp, i32, vp, i32, i64, i64, i64, i64, vp, vp, vp, i32, vp, vp, vp, vp]
+    L.tome_merge_wavg_ln.restype = i32
+    L.tome_merge_wavg_ln.argtypes = [vp, i32, vp, i32, i64, i64, i64, i64, vp, vp, vp, i32, vp, vp, vp, ctypes.c_float,
+                                     vp, vp, vp, vp]
     L.tome_merge_wavg_regrouped.restype = i32
     L.tome_merge_wavg_regrouped.argtypes = [vp, i32, vp, i32, i64, i64, i64, i64, i64, i32, vp, vp, vp, vp, vp, vp, vp]
     L.tome_merge.restype = i32
@@ -304,6 +308,43 @@ def merge_wavg(plan: MatchPlan, x: torch.Tensor, size: Optional[torch.Tensor]):
                                    _ptr(plan.edge_keep), x_out.data_ptr(), s_out.data_ptr(), _stream(x.device))
     _check(rc, "tome_merge_wavg")
     return x_out, s_out
+
+
+def ln_fusable(x: torch.Tensor, norm) -> bool:
+    """Can tome_merge_wavg_ln produce norm(x') for this LayerNorm module?"""
+    C = x.shape[-1]
+    return (isinstance(norm, torch.nn.LayerNorm) and norm.elementwise_affine and norm.bias is not None
+            and tuple(norm.normalized_shape) == (C,) and x.dtype in (torch.bfloat16, torch.float16)
+            and norm.weight.dtype == x.dtype and C % 8 == 0 and C <= 1024 and x.is_cuda
+            and not (torch.is_grad_enabled() and (x.requires_grad or norm.weight.requires_grad)))
+
+
+def merge_wavg_ln(plan: MatchPlan, x: torch.Tensor, size: Optional[torch.Tensor], weight: torch.Tensor,
+                  bias: torch.Tensor, eps: float):
+    """merge_wavg + LayerNorm of the merged tokens in one launch: returns (x_out, y_out, size_out)."""
+    x = _prep_x(plan, x, "merge_wavg_ln(x)", plan.T)
+    n, T, C = x.shape
+    xcode = dtype_code(x, "x")
+    if size is not None:
+        if size.shape != (n, T, 1):
+            raise TomeHipError(f"size must be [{n}, {T}, 1], got {tuple(size.shape)}")
+        if size.dtype not in (x.dtype, torch.float32):
+            size = size.to(x.dtype)
+        size = size.contiguous()
+        sdtype = size.dtype
+    else:
+        sdtype = x.dtype
+    x_out = torch.empty((n, T - plan.r, C), dtype=x.dtype, device=x.device)
+    y_out = torch.empty_like(x_out)
+    s_out = torch.empty((n, T - plan.r, 1), dtype=sdtype, device=x.device)
+    with _on_device(x.device):
+        rc = lib().tome_merge_wavg_ln(x.data_ptr(), xcode, _ptr(size), DTYPES[sdtype], n, T, C, plan.r,
+                                      plan.src_idx.data_ptr(), plan.dst_idx.data_ptr(), plan.unm_idx.data_ptr(),
+                                      int(plan.distill_token), _ptr(plan.edge_keep), weight.data_ptr(), bias.data_ptr(),
+                                      float(eps), x_out.data_ptr(), y_out.data_ptr(), s_out.data_ptr(),
+                                      _stream(x.device))
+    _check(rc, "tome_merge_wavg_ln")
+    return x_out, y_out, s_out
 
 
 def merge_wavg_regrouped(plan: MatchPlan, x_full: torch.Tensor, size: Optional[torch.Tensor], frames: int,

@@ -6,6 +6,7 @@ works on the reference's own model objects and on the host models of this reposi
 """
 from __future__ import annotations
 
+import os
 from typing import Callable, Dict, Tuple
 
 import torch
@@ -15,6 +16,7 @@ from ..merge import (bipartite_soft_matching, bipartite_soft_matching_drop, bipa
 from ..utils import parse_r
 
 _SUBCLASSES: Dict[Tuple[type, str], type] = {}
+_FUSE_LN = os.environ.get("TOME_FUSE_LN", "1") != "0"  # measurement switch: 0 = merge and LayerNorm as two steps
 
 
 def swizzle(module: torch.nn.Module, tag: str, methods: dict) -> None:
@@ -89,6 +91,30 @@ def reduce_merge(metric, x, info, r):
     if info["verbose"]:
         print(f"Merged {before} to {x.size(1)} tokens")
     return x
+
+
+def merge_then_norm(metric, x, info, norm, reduction_function, plain_merge_fn):
+    """The block step `x = reduction_function(metric, x, info); y = norm(x)` with the LayerNorm fused into the
+    merge kernel (tome_merge_wavg_ln) when this layer merges in plain 'merge' mode on 16-bit tokens; returns
+    (x, y).  Anything else runs the two steps as the reference does."""
+    from .. import _abi
+    from ..merge import do_nothing
+    r_list = info["r"]
+    if (_FUSE_LN and reduction_function is plain_merge_fn and r_list and r_list[0] > 0 and info["mode"] == "merge"
+            and _abi.ln_fusable(x, norm)):
+        r = r_list.pop(0)
+        merge, _ = bipartite_soft_matching(metric, r, info["class_token"], info["distill_token"], info["mode"])
+        if merge is do_nothing:
+            return x, norm(x)
+        if info["trace_source"]:
+            info["source"] = merge_source(merge, x, info["source"])
+        before = x.size(1)
+        x, y, info["size"] = _abi.merge_wavg_ln(merge.plan, x, info["size"], norm.weight, norm.bias, norm.eps)
+        if info["verbose"]:
+            print(f"Merged {before} to {x.size(1)} tokens")
+        return x, y
+    x = reduction_function(metric, x, info)
+    return x, norm(x)
 
 
 def reduce_merge_regrouped(metric, x_full, info, r, frames, hybrid=False):

@@ -23,8 +23,9 @@ def _block_forward(self, x):
     if self.gamma_1 is not None:
         attn = self.gamma_1 * attn
     x = x + self.drop_path(attn)
-    x = self.reduction_function(metric, x, info)
-    y = self.mlp(self.norm2(x))
+    # merge, then norm2 -- one kernel when the layer merges 16-bit tokens (tome_merge_wavg_ln)
+    x, y = C.merge_then_norm(metric, x, info, self.norm2, self.reduction_function, videomae_merge)
+    y = self.mlp(y)
     if self.gamma_2 is not None:
         y = self.gamma_2 * y
     return x + self.drop_path(y)

@@ -21,8 +21,10 @@ def _layer_forward(self, hidden_states, head_mask=None, output_attentions=False)
                           output_attentions=output_attentions)
     attention_output, metric, rest = outs[0], outs[1], outs[2:]
     hidden_states = attention_output + hidden_states
-    hidden_states = self.reduction_function(metric, hidden_states, info)
-    layer_output = self.intermediate(self.layernorm_after(hidden_states))
+    # merge, then layernorm_after -- one kernel when the layer merges 16-bit tokens (tome_merge_wavg_ln)
+    hidden_states, normed = C.merge_then_norm(metric, hidden_states, info, self.layernorm_after,
+                                              self.reduction_function, vivit_merge)
+    layer_output = self.intermediate(normed)
     layer_output = self.output(layer_output, hidden_states)  # second residual inside
     return (layer_output,) + rest
 
