@@ -374,7 +374,12 @@ static int launch_merge_rows(const void *x, const void *size, int64_t n, int64_t
             int v = e ? atoi(e) : 0;
             return (v == 3 || v == 6) ? v : 6;
         }();
-        const int nit = (cpr <= 3 * WAVE && !ln_p) ? nit_pref : FAST_NIT;
+        static const int nit_ln = [] {
+            const char *e = getenv("TOME_MERGE_LN_NIT");
+            int v = e ? atoi(e) : 0;
+            return (v == 3 || v == 6) ? v : 6;
+        }();
+        const int nit = (cpr <= 3 * WAVE) ? (ln_p ? nit_ln : nit_pref) : FAST_NIT;
         int R = (int)((nit * WAVE) / cpr);
         if (R > FAST_MAXR) R = FAST_MAXR;
         const int64_t waves = n * ((To + R - 1) / R) + (OP == OP_DROP ? 0 : n * r) + cls_rows;
@@ -383,10 +388,16 @@ static int launch_merge_rows(const void *x, const void *size, int64_t n, int64_t
             if (OP != OP_WAVG || sizeof(TX) != 2 || cpr > 2 * WAVE || !aligned16(ln_p->y) || !aligned16(ln_p->weight) ||
                 !aligned16(ln_p->bias))
                 return fail(TOME_EINVAL, "fused LayerNorm needs 16-bit tokens with C <= 1024 and 16-byte aligned buffers");
-            if constexpr (OP == OP_WAVG && sizeof(TX) == 2)
-                hipLaunchKernelGGL((k_merge_rows_fast<TX, TS, OP, 6, true>), grid, dim3(256), 0, st, (const TX *)x,
-                                   (const TS *)size, (int)n, (int)T, (int)C, (int)r, R, (int)cpr, src, dst, unm, distill,
-                                   keep, (TX *)xout, (TS *)sout, lin, lout, cls_rows, *ln_p);
+            if constexpr (OP == OP_WAVG && sizeof(TX) == 2) {
+                if (nit == 3)
+                    hipLaunchKernelGGL((k_merge_rows_fast<TX, TS, OP, 3, true>), grid, dim3(256), 0, st, (const TX *)x,
+                                       (const TS *)size, (int)n, (int)T, (int)C, (int)r, R, (int)cpr, src, dst, unm,
+                                       distill, keep, (TX *)xout, (TS *)sout, lin, lout, cls_rows, *ln_p);
+                else
+                    hipLaunchKernelGGL((k_merge_rows_fast<TX, TS, OP, 6, true>), grid, dim3(256), 0, st, (const TX *)x,
+                                       (const TS *)size, (int)n, (int)T, (int)C, (int)r, R, (int)cpr, src, dst, unm,
+                                       distill, keep, (TX *)xout, (TS *)sout, lin, lout, cls_rows, *ln_p);
+            }
         } else if (nit == 3)
             hipLaunchKernelGGL((k_merge_rows_fast<TX, TS, OP, 3>), grid, dim3(256), 0, st, (const TX *)x,
                                (const TS *)size, (int)n, (int)T, (int)C, (int)r, R, (int)cpr, src, dst, unm, distill,

@@ -505,45 +505,33 @@ __global__ __launch_bounds__(256) void k_merge_rows_fast(const TX *__restrict__ 
         if (LN) raw[it] = outv;  // keep the stored bits: LayerNorm runs on exactly what was written
     }
     if (LN) {
-        // statistics of the (up to) four rows of this wave: per-lane partials by row, then wave sums
-        float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+        // statistics of the (up to) four rows of this wave in one pass over the registers: per-lane sums and
+        // sums of squares by row, eight independent wave reductions, var = E[x^2] - mean^2 (fp32; the tokens
+        // are 16-bit values of order one, so the cancellation costs ~1e-6 relative -- far below their epsilon)
+        float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f, q0 = 0.0f, q1 = 0.0f, q2 = 0.0f, q3 = 0.0f;
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int rr = rowof[it];
             Pack<TX, VEC> pk;
             __builtin_memcpy(&pk, &raw[it], 16);
-            float t = 0.0f;
+            float t = 0.0f, u = 0.0f;
 #pragma unroll
-            for (int e = 0; e < VEC; ++e) t += to_f32(pk.e[e]);
-            s0 += rr == 0 ? t : 0.0f;
-            s1 += rr == 1 ? t : 0.0f;
-            s2 += rr == 2 ? t : 0.0f;
-            s3 += rr == 3 ? t : 0.0f;
+            for (int e = 0; e < VEC; ++e) {
+                const float v = to_f32(pk.e[e]);
+                t += v;
+                u = __fmaf_rn(v, v, u);
+            }
+            s0 += rr == 0 ? t : 0.0f; q0 += rr == 0 ? u : 0.0f;
+            s1 += rr == 1 ? t : 0.0f; q1 += rr == 1 ? u : 0.0f;
+            s2 += rr == 2 ? t : 0.0f; q2 += rr == 2 ? u : 0.0f;
+            s3 += rr == 3 ? t : 0.0f; q3 += rr == 3 ? u : 0.0f;
         }
         const float fc = (float)C;
         const float m0 = wave_sum(s0) / fc, m1 = wave_sum(s1) / fc, m2 = wave_sum(s2) / fc, m3 = wave_sum(s3) / fc;
-        s0 = s1 = s2 = s3 = 0.0f;
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const int rr = rowof[it];
-            const float m = rr == 0 ? m0 : (rr == 1 ? m1 : (rr == 2 ? m2 : m3));
-            Pack<TX, VEC> pk;
-            __builtin_memcpy(&pk, &raw[it], 16);
-            float t = 0.0f;
-#pragma unroll
-            for (int e = 0; e < VEC; ++e) {
-                const float d = to_f32(pk.e[e]) - m;
-                t += d * d;
-            }
-            s0 += rr == 0 ? t : 0.0f;
-            s1 += rr == 1 ? t : 0.0f;
-            s2 += rr == 2 ? t : 0.0f;
-            s3 += rr == 3 ? t : 0.0f;
-        }
-        const float r0 = 1.0f / __builtin_sqrtf(wave_sum(s0) / fc + ln.eps),
-                    r1 = 1.0f / __builtin_sqrtf(wave_sum(s1) / fc + ln.eps),
-                    r2 = 1.0f / __builtin_sqrtf(wave_sum(s2) / fc + ln.eps),
-                    r3 = 1.0f / __builtin_sqrtf(wave_sum(s3) / fc + ln.eps);
+        const float v0 = fmaxf(wave_sum(q0) / fc - m0 * m0, 0.0f), v1 = fmaxf(wave_sum(q1) / fc - m1 * m1, 0.0f),
+                    v2 = fmaxf(wave_sum(q2) / fc - m2 * m2, 0.0f), v3 = fmaxf(wave_sum(q3) / fc - m3 * m3, 0.0f);
+        const float r0 = 1.0f / __builtin_sqrtf(v0 + ln.eps), r1 = 1.0f / __builtin_sqrtf(v1 + ln.eps),
+                    r2 = 1.0f / __builtin_sqrtf(v2 + ln.eps), r3 = 1.0f / __builtin_sqrtf(v3 + ln.eps);
         const TX *lw = reinterpret_cast<const TX *>(ln.weight), *lb = reinterpret_cast<const TX *>(ln.bias);
         TX *yg = group_ptr(reinterpret_cast<TX *>(ln.y), lout, g);
 #pragma unroll
