@@ -122,12 +122,15 @@ int tome_merge_wavg(const void *x, int x_dtype, const void *size, int size_dtype
  * x_out as tome_merge_wavg; y_out [n,T-r,C] = LayerNorm(x_out) over the channels (weight, bias [C] of the token
  * dtype, eps), computed in fp32 from the stored x_out and rounded once -- so the MLP reads y_out and the
  * separate LayerNorm pass over the merged tokens disappears.  16-bit tokens, C <= 1024, C % 8 == 0.
+ * addend: NULL, or [n,T,C] like x: the tokens that are merged are round_to_dtype(x + addend), i.e. the residual
+ * `x = x + attn(norm1(x))` in front of the merge (videomae.py:20, vivit.py:35) is taken while loading and the
+ * separate add pass disappears as well.
  */
 int tome_merge_wavg_ln(const void *x, int x_dtype, const void *size, int size_dtype, int64_t n, int64_t T,
                        int64_t C, int64_t r, const int64_t *src_idx, const int64_t *dst_idx,
                        const int64_t *unm_idx, int distill_token, const uint8_t *edge_keep,
-                       const void *ln_weight, const void *ln_bias, float eps, void *x_out, void *y_out,
-                       void *size_out, tome_stream_t stream);
+                       const void *ln_weight, const void *ln_bias, float eps, const void *addend, void *x_out,
+                       void *y_out, void *size_out, tome_stream_t stream);
 
 /*
  * tome_merge_wavg_regrouped  <-  the rearrange / merge_wavg / rearrange / cat sequence of

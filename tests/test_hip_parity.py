@@ -507,3 +507,24 @@ def test_merge_wavg_ln_fused(n, T, C, r, cls, dtype, tol):
     ref = torch.nn.functional.layer_norm(want_x.float(), (C,), w.float(), b.float(), 1e-6)
     err = (got_y.float() - ref).abs()
     assert float((err / ref.abs().clamp(min=1.0)).max()) <= tol, float(err.max())
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("n,T,C,r,cls", [(3, 197, 768, 16, True), (2, 64, 64, 30, False), (2, 392, 768, 150, False)])
+def test_merge_wavg_ln_fused_residual(n, T, C, r, cls, dtype):
+    """tome_merge_wavg_ln with an addend == the same call on the pre-added tokens (torch's `x + a`, rounded to
+    the dtype), bit for bit, for x', y and sizes."""
+    from tome import _abi
+    tm = _tome()
+    seed = 77 * n + T + C
+    metric = dev(synth.normal_like((n, T, 64), seed))
+    x = dev(synth.normal_like((n, T, C), seed + 1), dtype)
+    a = dev(0.5 * synth.normal_like((n, T, C), seed + 5), dtype)
+    size = dev(synth.small_ints((n, T, 1), seed + 2, 1, 4), dtype)
+    w = dev(1.0 + 0.1 * synth.normal_like((C,), seed + 3), dtype)
+    b = dev(0.1 * synth.normal_like((C,), seed + 4), dtype)
+    merge, _ = tm.bipartite_soft_matching(metric, r, cls)
+    want = _abi.merge_wavg_ln(merge.plan, x + a, size, w, b, 1e-6)
+    got = _abi.merge_wavg_ln(merge.plan, x, size, w, b, 1e-6, addend=a)
+    for g_, w_ in zip(got, want):
+        assert torch.equal(g_, w_)

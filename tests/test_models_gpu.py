@@ -212,3 +212,35 @@ def test_config0_videomae_b_fp32_vs_cpu_port():
     err = (got.cpu() - want).abs().max().item()
     scale = want.abs().max().item()
     assert err <= 2e-3 + 2e-2 * scale, (err, scale)
+
+
+@pytest.mark.parametrize("host_name", ["videomae", "vivit"])
+def test_fused_block_equals_unfused_block_bf16(host_name, monkeypatch):
+    """bf16 forward with the residual add + merge + LayerNorm fused into one kernel (tome_merge_wavg_ln) vs the
+    same forward running the three steps separately: identical token schedule and first-layer indices, final
+    sizes identical, logits within bf16 rounding noise."""
+    tome, H = _hosts()
+    from tome.patch import _common
+    torch.manual_seed(0)
+    if host_name == "videomae":
+        model = H["videomae"].VideoMAE(num_frames=8, img_size=64, patch_size=16, embed_dim=64, depth=4, num_heads=1,
+                                       num_classes=9)
+        patch, frames = tome.patch.videomae, 8
+    else:
+        model = H["vivit"].ViViT(num_classes=9, image_size=64, num_frames=8, hidden_size=64, num_hidden_layers=4,
+                                 num_attention_heads=1, intermediate_size=128)
+        patch, frames = tome.patch.vivit, 8
+    model = model.to(DEV).to(torch.bfloat16).eval()
+    patch(model)
+    clip = torch.rand(3, 3, frames, 64, 64, device=DEV).to(torch.bfloat16)
+    outs = {}
+    for fused in (True, False):
+        monkeypatch.setattr(_common, "_FUSE_LN", fused)
+        monkeypatch.setattr(_common, "_FUSE_ADD", fused)
+        out, plans = _trace(tome, model, clip, 5)
+        outs[fused] = (out.float(), plans, model._tome_info["size"].float().clone())
+    (o1, p1, s1), (o0, p0, s0) = outs[True], outs[False]
+    assert [s[1] for s, _ in p1] == [s[1] for s, _ in p0]
+    assert torch.equal(p1[0][1].src_idx, p0[0][1].src_idx) and torch.equal(p1[0][1].dst_idx, p0[0][1].dst_idx)
+    assert float(s1.sum()) == float(s0.sum())
+    assert float((o1 - o0).abs().max()) <= 0.05 * max(1.0, float(o0.abs().max()))

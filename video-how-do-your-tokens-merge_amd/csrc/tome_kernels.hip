@@ -365,7 +365,7 @@ static int launch_merge_rows(const void *x, const void *size, int64_t n, int64_t
     const TokLayout lout = lout_p ? *lout_p : contiguous_layout(To, C);
     const bool vec_ok = (C % VEC == 0) && aligned16(x) && aligned16(xout);
     const int64_t cpr = C / VEC;  // 16-byte chunks per row
-    const LnArgs no_ln{nullptr, nullptr, nullptr, 0.0f};
+    const LnArgs no_ln{nullptr, nullptr, nullptr, 0.0f, nullptr};
     if (vec_ok && cpr <= FAST_NIT * WAVE) {
         // rows per wave: measured on MI355X, NIT=6 (four 1536-byte rows per wave for 768-channel bf16 tokens)
         // beats NIT=3 by ~4 %; TOME_MERGE_NIT=3 keeps the other variant reachable for re-measurement
@@ -454,12 +454,13 @@ extern "C" int tome_merge_wavg(const void *x, int x_dtype, const void *size, int
 extern "C" int tome_merge_wavg_ln(const void *x, int x_dtype, const void *size, int size_dtype, int64_t n, int64_t T,
                                   int64_t C, int64_t r, const int64_t *src_idx, const int64_t *dst_idx,
                                   const int64_t *unm_idx, int distill_token, const uint8_t *edge_keep,
-                                  const void *ln_weight, const void *ln_bias, float eps, void *x_out, void *y_out,
-                                  void *size_out, tome_stream_t stream) {
+                                  const void *ln_weight, const void *ln_bias, float eps, const void *addend,
+                                  void *x_out, void *y_out, void *size_out, tome_stream_t stream) {
     if (int rc = check_merge_args("tome_merge_wavg_ln", x, n, T, C, r, x_out)) return rc;
+    if (addend && !aligned16(addend)) return fail(TOME_EINVAL, "tome_merge_wavg_ln: addend not 16-byte aligned");
     if (!src_idx || !dst_idx || (!unm_idx && (T + 1) / 2 > r) || !size_out || !y_out || !ln_weight || !ln_bias)
         return fail(TOME_EINVAL, "tome_merge_wavg_ln: null buffer");
-    const LnArgs ln{ln_weight, ln_bias, y_out, eps};
+    const LnArgs ln{ln_weight, ln_bias, y_out, eps, addend};
     hipStream_t st = (hipStream_t)stream;
 #define WAVGLN(TX, TS)                                                                                         \
     return launch_merge_rows<TX, TS, OP_WAVG>(x, size, n, T, C, r, src_idx, dst_idx, unm_idx, distill_token,   \

@@ -34,7 +34,18 @@ struct LnArgs {
     const void *weight, *bias;  // [C] of the token dtype
     void *y;                    // [n, T-r, C] of the token dtype, same row layout as x_out
     float eps;
+    const void *addend;         // optional [n, T, C]: the tokens that are merged are round(x + addend), i.e. the
+                                // block's residual `x = x + attn(...)` (videomae.py:20,25) is taken on the fly
 };
+
+// round(x + a) in the token dtype, element-wise on two 16-byte packs (what torch's `x + a` stores)
+template <typename TX, int VEC>
+__device__ __forceinline__ Pack<TX, VEC> add_packs(const Pack<TX, VEC> &x, const Pack<TX, VEC> &a) {
+    Pack<TX, VEC> o;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) o.e[e] = from_f32<TX>(__fadd_rn(to_f32(x.e[e]), to_f32(a.e[e])));
+    return o;
+}
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -56,7 +67,8 @@ __device__ __forceinline__ void merge_dst_row(const TX *__restrict__ xg, const T
                                               const int64_t *__restrict__ srcg,
                                               const int64_t *__restrict__ dstg, const uint8_t *__restrict__ keep,
                                               TX *__restrict__ orow, TS *__restrict__ srow, int lane,
-                                              const LnArgs *ln = nullptr, TX *__restrict__ yrow = nullptr) {
+                                              const LnArgs *ln = nullptr, TX *__restrict__ yrow = nullptr,
+                                              const TX *__restrict__ ag = nullptr) {
     const int t = 2 * j + 1;
     const TX *xr = xg + (int64_t)t * tstride;
     float s_own = 1.0f;
@@ -67,9 +79,23 @@ __device__ __forceinline__ void merge_dst_row(const TX *__restrict__ xg, const T
     if (narrow_row) {
         const int c0 = lane * VEC, c1 = (WAVE + lane) * VEC;
         const bool a0 = c0 < C, a1 = c1 < C;
+        typedef Pack<TX, VEC> __attribute__((aligned(sizeof(TX) * VEC))) PKA;
         float acc0[VEC], acc1[VEC];
-        if (a0) load_pack<TX, VEC>(xr + c0, acc0);
-        if (a1) load_pack<TX, VEC>(xr + c1, acc1);
+        if (LN && ag) {
+            const TX *ar = ag + (int64_t)t * tstride;
+            PKA x0, x1, y0, y1;
+            if (a0) { x0 = *reinterpret_cast<const PKA *>(xr + c0); y0 = *reinterpret_cast<const PKA *>(ar + c0); }
+            if (a1) { x1 = *reinterpret_cast<const PKA *>(xr + c1); y1 = *reinterpret_cast<const PKA *>(ar + c1); }
+            if (a0) { const Pack<TX, VEC> s0 = add_packs<TX, VEC>(x0, y0);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) acc0[e] = to_f32(s0.e[e]); }
+            if (a1) { const Pack<TX, VEC> s1 = add_packs<TX, VEC>(x1, y1);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) acc1[e] = to_f32(s1.e[e]); }
+        } else {
+            if (a0) load_pack<TX, VEC>(xr + c0, acc0);
+            if (a1) load_pack<TX, VEC>(xr + c1, acc1);
+        }
         // hybrid: does any incoming edge fall below the threshold (merge.py:326)?
         bool kill = false;
         if (keep && OP != OP_DROP) {
@@ -115,6 +141,7 @@ __device__ __forceinline__ void merge_dst_row(const TX *__restrict__ xg, const T
                 for (int e0 = 0; e0 < nsrc; e0 += NB) {
                     typedef Pack<TX, VEC> __attribute__((aligned(sizeof(TX) * VEC))) PK;
                     PK p0[NB], p1[NB];  // raw chunks of up to NB source rows, all in flight together
+                    PK q0[NB], q1[NB];  // ... and of the addend rows when the residual is fused
                     float sq[NB];
 #pragma unroll
                     for (int u = 0; u < NB; ++u) {
@@ -124,6 +151,18 @@ __device__ __forceinline__ void merge_dst_row(const TX *__restrict__ xg, const T
                         const TX *sr = xg + (int64_t)tsu * tstride;
                         if (a0) p0[u] = *reinterpret_cast<const PK *>(sr + c0);
                         if (a1) p1[u] = *reinterpret_cast<const PK *>(sr + c1);
+                        if (LN && ag) {
+                            const TX *sa = ag + (int64_t)tsu * tstride;
+                            if (a0) q0[u] = *reinterpret_cast<const PK *>(sa + c0);
+                            if (a1) q1[u] = *reinterpret_cast<const PK *>(sa + c1);
+                        }
+                    }
+                    if (LN && ag) {
+#pragma unroll
+                        for (int u = 0; u < NB; ++u) {
+                            if (a0) p0[u] = add_packs<TX, VEC>(p0[u], q0[u]);
+                            if (a1) p1[u] = add_packs<TX, VEC>(p1[u], q1[u]);
+                        }
                     }
 #pragma unroll
                     for (int u = 0; u < NB; ++u) {
@@ -397,7 +436,8 @@ __global__ __launch_bounds__(256) void k_merge_rows_fast(const TX *__restrict__ 
             group_ptr(x, lin, g), size ? size + (int64_t)g * T_ : nullptr, C, lin.tok_stride, r, g, j,
             src_idx + (int64_t)g * r, dstg, keep, group_ptr(xout, lout, g) + (int64_t)o * lout.tok_stride,
             sout ? sout + (int64_t)g * To + o : nullptr, lane, &ln,
-            LN ? group_ptr(reinterpret_cast<TX *>(ln.y), lout, g) + (int64_t)o * lout.tok_stride : nullptr);
+            LN ? group_ptr(reinterpret_cast<TX *>(ln.y), lout, g) + (int64_t)o * lout.tok_stride : nullptr,
+            (LN && ln.addend) ? group_ptr(reinterpret_cast<const TX *>(ln.addend), lin, g) : nullptr);
         return;
     }
     const int g = (int)(w / rg_per_group);
@@ -473,6 +513,29 @@ __global__ __launch_bounds__(256) void k_merge_rows_fast(const TX *__restrict__ 
         if (ok)
             raw[it] = *reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(xg + (int64_t)t * lin.tok_stride) +
                                                        cc * 16);
+    }
+    if (LN && ln.addend) {  // fused residual: the rows that are merged are round(x + addend)
+        const TX *agp = group_ptr(reinterpret_cast<const TX *>(ln.addend), lin, g);
+        uint4 rawa[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int rr = rowof[it];
+            if (rr < 0) continue;
+            const int q = it * WAVE + lane;
+            const int cc = q - rr * cpr;
+            const int t = rr == 0 ? tok0 : (rr == 1 ? tok1 : (rr == 2 ? tok2 : tok3));
+            rawa[it] = *reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(agp + (int64_t)t * lin.tok_stride) +
+                                                        cc * 16);
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            if (rowof[it] < 0) continue;
+            Pack<TX, VEC> px, pa;
+            __builtin_memcpy(&px, &raw[it], 16);
+            __builtin_memcpy(&pa, &rawa[it], 16);
+            const Pack<TX, VEC> ps = add_packs<TX, VEC>(px, pa);
+            __builtin_memcpy(&raw[it], &ps, 16);
+        }
     }
     if (load_size) my_s = to_f32(my_s_raw);
     const float sz0 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(my_s), 0)),

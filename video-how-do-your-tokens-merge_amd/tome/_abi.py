@@ -67,7 +67,7 @@ def lib() -> ctypes.CDLL:
     L.tome_merge_wavg.argtypes = [vp, i32, vp, i32, i64, i64, i64, i64, vp, vp, vp, i32, vp, vp, vp, vp]
     L.tome_merge_wavg_ln.restype = i32
     L.tome_merge_wavg_ln.argtypes = [vp, i32, vp, i32, i64, i64, i64, i64, vp, vp, vp, i32, vp, vp, vp, ctypes.c_float,
-                                     vp, vp, vp, vp]
+                                     vp, vp, vp, vp, vp]
     L.tome_merge_wavg_regrouped.restype = i32
     L.tome_merge_wavg_regrouped.argtypes = [vp, i32, vp, i32, i64, i64, i64, i64, i64, i32, vp, vp, vp, vp, vp, vp, vp]
     L.tome_merge.restype = i32
@@ -320,10 +320,15 @@ def ln_fusable(x: torch.Tensor, norm) -> bool:
 
 
 def merge_wavg_ln(plan: MatchPlan, x: torch.Tensor, size: Optional[torch.Tensor], weight: torch.Tensor,
-                  bias: torch.Tensor, eps: float):
-    """merge_wavg + LayerNorm of the merged tokens in one launch: returns (x_out, y_out, size_out)."""
+                  bias: torch.Tensor, eps: float, addend: Optional[torch.Tensor] = None):
+    """merge_wavg + LayerNorm of the merged tokens in one launch: returns (x_out, y_out, size_out).  With
+    `addend` the merged tokens are `x + addend` (the residual in front of the merge, added while loading)."""
     x = _prep_x(plan, x, "merge_wavg_ln(x)", plan.T)
     n, T, C = x.shape
+    if addend is not None:
+        if addend.shape != x.shape or addend.dtype != x.dtype or addend.device != x.device:
+            raise TomeHipError("merge_wavg_ln: addend must match x in shape, dtype and device")
+        addend = addend if addend.is_contiguous() else addend.contiguous()
     xcode = dtype_code(x, "x")
     if size is not None:
         if size.shape != (n, T, 1):
@@ -341,7 +346,7 @@ def merge_wavg_ln(plan: MatchPlan, x: torch.Tensor, size: Optional[torch.Tensor]
         rc = lib().tome_merge_wavg_ln(x.data_ptr(), xcode, _ptr(size), DTYPES[sdtype], n, T, C, plan.r,
                                       plan.src_idx.data_ptr(), plan.dst_idx.data_ptr(), plan.unm_idx.data_ptr(),
                                       int(plan.distill_token), _ptr(plan.edge_keep), weight.data_ptr(), bias.data_ptr(),
-                                      float(eps), x_out.data_ptr(), y_out.data_ptr(), s_out.data_ptr(),
+                                      float(eps), _ptr(addend), x_out.data_ptr(), y_out.data_ptr(), s_out.data_ptr(),
                                       _stream(x.device))
     _check(rc, "tome_merge_wavg_ln")
     return x_out, y_out, s_out

@@ -17,6 +17,7 @@ from ..utils import parse_r
 
 _SUBCLASSES: Dict[Tuple[type, str], type] = {}
 _FUSE_LN = os.environ.get("TOME_FUSE_LN", "1") != "0"  # measurement switch: 0 = merge and LayerNorm as two steps
+_FUSE_ADD = os.environ.get("TOME_FUSE_ADD", "1") != "0"  # measurement switch: 0 = residual add as its own pass
 
 
 def swizzle(module: torch.nn.Module, tag: str, methods: dict) -> None:
@@ -93,23 +94,33 @@ def reduce_merge(metric, x, info, r):
     return x
 
 
-def merge_then_norm(metric, x, info, norm, reduction_function, plain_merge_fn):
-    """The block step `x = reduction_function(metric, x, info); y = norm(x)` with the LayerNorm fused into the
-    merge kernel (tome_merge_wavg_ln) when this layer merges in plain 'merge' mode on 16-bit tokens; returns
-    (x, y).  Anything else runs the two steps as the reference does."""
+def merge_then_norm(metric, x, info, norm, reduction_function, plain_merge_fn, residual=None):
+    """The block steps `[x = x + residual;] x = reduction_function(metric, x, info); y = norm(x)` with the
+    residual add and the LayerNorm fused into the merge kernel (tome_merge_wavg_ln) when this layer merges in
+    plain 'merge' mode on 16-bit tokens; returns (x, y).  Anything else runs the steps as the reference does."""
     from .. import _abi
     from ..merge import do_nothing
     r_list = info["r"]
+    if residual is not None and not (_FUSE_LN and _FUSE_ADD and reduction_function is plain_merge_fn and r_list
+                                     and r_list[0] > 0 and info["mode"] == "merge" and not info["trace_source"]
+                                     and _abi.ln_fusable(x, norm) and residual.dtype == x.dtype
+                                     and _abi.effective_r(x.shape[1], r_list[0], info["class_token"],
+                                                          info["distill_token"]) > 0):
+        x = x + residual
+        residual = None
     if (_FUSE_LN and reduction_function is plain_merge_fn and r_list and r_list[0] > 0 and info["mode"] == "merge"
             and _abi.ln_fusable(x, norm)):
         r = r_list.pop(0)
         merge, _ = bipartite_soft_matching(metric, r, info["class_token"], info["distill_token"], info["mode"])
         if merge is do_nothing:
+            if residual is not None:
+                x = x + residual
             return x, norm(x)
         if info["trace_source"]:
             info["source"] = merge_source(merge, x, info["source"])
         before = x.size(1)
-        x, y, info["size"] = _abi.merge_wavg_ln(merge.plan, x, info["size"], norm.weight, norm.bias, norm.eps)
+        x, y, info["size"] = _abi.merge_wavg_ln(merge.plan, x, info["size"], norm.weight, norm.bias, norm.eps,
+                                                addend=residual)
         if info["verbose"]:
             print(f"Merged {before} to {x.size(1)} tokens")
         return x, y

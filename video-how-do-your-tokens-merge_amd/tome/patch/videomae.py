@@ -22,9 +22,10 @@ def _block_forward(self, x):
     attn, metric = self.attn(self.norm1(x), attn_size, info["head_aggregation"])
     if self.gamma_1 is not None:
         attn = self.gamma_1 * attn
-    x = x + self.drop_path(attn)
-    # merge, then norm2 -- one kernel when the layer merges 16-bit tokens (tome_merge_wavg_ln)
-    x, y = C.merge_then_norm(metric, x, info, self.norm2, self.reduction_function, videomae_merge)
+    # x = x + attn; x = merge(x); y = norm2(x) -- one kernel when the layer merges 16-bit tokens
+    # (tome_merge_wavg_ln with the residual as addend), the three steps of the reference otherwise
+    x, y = C.merge_then_norm(metric, x, info, self.norm2, self.reduction_function, videomae_merge,
+                             residual=self.drop_path(attn))
     y = self.mlp(y)
     if self.gamma_2 is not None:
         y = self.gamma_2 * y

@@ -20,10 +20,10 @@ def _layer_forward(self, hidden_states, head_mask=None, output_attentions=False)
     outs = self.attention(self.layernorm_before(hidden_states), attn_size, info["head_aggregation"], head_mask,
                           output_attentions=output_attentions)
     attention_output, metric, rest = outs[0], outs[1], outs[2:]
-    hidden_states = attention_output + hidden_states
-    # merge, then layernorm_after -- one kernel when the layer merges 16-bit tokens (tome_merge_wavg_ln)
+    # first residual, merge, layernorm_after -- one kernel when the layer merges 16-bit tokens
+    # (tome_merge_wavg_ln with the attention output as addend), the three steps of the reference otherwise
     hidden_states, normed = C.merge_then_norm(metric, hidden_states, info, self.layernorm_after,
-                                              self.reduction_function, vivit_merge)
+                                              self.reduction_function, vivit_merge, residual=attention_output)
     layer_output = self.intermediate(normed)
     layer_output = self.output(layer_output, hidden_states)  # second residual inside
     return (layer_output,) + rest
