@@ -109,8 +109,9 @@ def measure_kernels(batch: int, t0: int, r: int, dev, reps: int = 10):
         stats["k_scores_rowmax"]["flops"] += batch * 2 * t1 * t2 * HEAD_DIM
         stats["k_scores_rowmax"]["bytes"] += batch * t * HEAD_DIM * 4
         stats["k_rank_select"]["bytes"] += batch * (t1 * 8 + t1 * 8)
-        # --- merge + the block's norm2: one kernel per call (tome_merge_wavg_ln, what the patched block runs),
-        # timed over back-to-back launches with preallocated outputs
+        # --- residual add + merge + the block's norm2: one kernel per call (tome_merge_wavg_ln with addend, what
+        # the patched block runs), timed over back-to-back launches with preallocated outputs
+        res = (0.1 * torch.randn(batch, t, EMBED, device=dev, generator=g)).bfloat16()
         x_out = torch.empty(batch, t - re, EMBED, device=dev, dtype=torch.bfloat16)
         y_out = torch.empty_like(x_out)
         s_out = torch.empty(batch, t - re, 1, device=dev, dtype=torch.bfloat16)
@@ -119,7 +120,8 @@ def measure_kernels(batch: int, t0: int, r: int, dev, reps: int = 10):
         def launch():
             rc = L.tome_merge_wavg_ln(x.data_ptr(), 1, sp, 1, batch, t, EMBED, re, plan.src_idx.data_ptr(),
                                       plan.dst_idx.data_ptr(), plan.unm_idx.data_ptr(), 0, None, ln_w.data_ptr(),
-                                      ln_b.data_ptr(), 1e-6, x_out.data_ptr(), y_out.data_ptr(), s_out.data_ptr(), st)
+                                      ln_b.data_ptr(), 1e-6, res.data_ptr(), x_out.data_ptr(), y_out.data_ptr(),
+                                      s_out.data_ptr(), st)
             assert rc == 0
         for _ in range(2):
             launch()
@@ -131,9 +133,9 @@ def measure_kernels(batch: int, t0: int, r: int, dev, reps: int = 10):
         e1.synchronize()
         stats["k_merge_rows"]["ms"] += e0.elapsed_time(e1) / reps
         stats["k_merge_rows"]["launches"] += 1
-        # SURVEY 8d (read x and size once, write x' and size' once; bf16 tokens and sizes) + the fused norm2's
-        # own output y = LayerNorm(x') (its input never leaves the kernel)
-        stats["k_merge_rows"]["bytes"] += batch * (t * EMBED * 2 + t * 2 + 2 * (t - re) * EMBED * 2 + (t - re) * 2)
+        # SURVEY 8d (read x and size once, write x' and size' once; bf16 tokens and sizes) + the fused residual's
+        # second input and the fused norm2's own output y = LayerNorm(x') (its input never leaves the kernel)
+        stats["k_merge_rows"]["bytes"] += batch * (2 * t * EMBED * 2 + t * 2 + 2 * (t - re) * EMBED * 2 + (t - re) * 2)
         x, size = x_out, s_out
     return stats
 
