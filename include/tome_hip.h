@@ -147,6 +147,16 @@ int tome_merge_wavg_regrouped(const void *x, int x_dtype, const void *size, int 
                               const int64_t *src_idx, const int64_t *dst_idx, const int64_t *unm_idx,
                               const uint8_t *edge_keep, void *x_out, void *size_out, tome_stream_t stream);
 
+/* tome_merge_wavg_regrouped with the residual add in front and the block's norm2 behind it fused in, as
+ * tome_merge_wavg_ln does for the plain layout (timesformer.py:52-56, motionformer.py:24-29).  The class-token
+ * rows get the same add + LayerNorm.  16-bit tokens, C <= 1024. */
+int tome_merge_wavg_regrouped_ln(const void *x, int x_dtype, const void *size, int size_dtype, int64_t B,
+                                 int64_t F, int64_t P, int64_t C, int64_t r, int has_cls,
+                                 const int64_t *src_idx, const int64_t *dst_idx, const int64_t *unm_idx,
+                                 const uint8_t *edge_keep, const void *ln_weight, const void *ln_bias, float eps,
+                                 const void *addend, void *x_out, void *y_out, void *size_out,
+                                 tome_stream_t stream);
+
 /* tome_merge  <-  merge(x, mode) closure (merge.py:75-85; hybrid :313-334 when edge_keep). */
 int tome_merge(const void *x, int dtype, int64_t n, int64_t T, int64_t C, int64_t r,
                const int64_t *src_idx, const int64_t *dst_idx, const int64_t *unm_idx,

@@ -528,3 +528,27 @@ def test_merge_wavg_ln_fused_residual(n, T, C, r, cls, dtype):
     got = _abi.merge_wavg_ln(merge.plan, x, size, w, b, 1e-6, addend=a)
     for g_, w_ in zip(got, want):
         assert torch.equal(g_, w_)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("B,F,P,C,r", [(2, 4, 36, 64, 6), (2, 8, 196, 768, 16), (1, 8, 49, 1024, 24)])
+def test_merge_wavg_regrouped_ln(B, F, P, C, r, dtype):
+    """tome_merge_wavg_regrouped_ln (residual + merge on the interleaved layout + LayerNorm, class-token rows
+    included) == add, tome_merge_wavg_regrouped, then an fp32 LayerNorm of the stored tokens."""
+    from tome import _abi
+    tm = _tome()
+    seed = 1300 + B * F + P
+    x_full = dev(synth.normal_like((B, 1 + P * F, C), seed), dtype)
+    res = dev(0.5 * synth.normal_like((B, 1 + P * F, C), seed + 9), dtype)
+    size = dev(synth.small_ints((B * F, P, 1), seed + 2, 1, 4), dtype)
+    w = dev(1.0 + 0.1 * synth.normal_like((C,), seed + 3), dtype)
+    b = dev(0.1 * synth.normal_like((C,), seed + 4), dtype)
+    metric = dev(synth.normal_like((B * F, P, 16), seed + 5))
+    merge, _ = tm.bipartite_soft_matching(metric, r)
+    plan = merge.plan
+    want_x, want_s = _abi.merge_wavg_regrouped(plan, x_full + res, size, F, has_cls=True)
+    got_x, got_y, got_s = _abi.merge_wavg_regrouped(plan, x_full, size, F, has_cls=True, ln=(w, b, 1e-6), addend=res)
+    assert torch.equal(got_x, want_x) and torch.equal(got_s, want_s)
+    ref = torch.nn.functional.layer_norm(want_x.float(), (C,), w.float(), b.float(), 1e-6)
+    tol = 2 ** -7 if dtype == torch.bfloat16 else 2 ** -10
+    assert float(((got_y.float() - ref).abs() / ref.abs().clamp(min=1.0)).max()) <= tol

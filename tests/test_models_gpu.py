@@ -214,7 +214,7 @@ def test_config0_videomae_b_fp32_vs_cpu_port():
     assert err <= 2e-3 + 2e-2 * scale, (err, scale)
 
 
-@pytest.mark.parametrize("host_name", ["videomae", "vivit"])
+@pytest.mark.parametrize("host_name", ["videomae", "vivit", "timesformer", "motionformer"])
 def test_fused_block_equals_unfused_block_bf16(host_name, monkeypatch):
     """bf16 forward with the residual add + merge + LayerNorm fused into one kernel (tome_merge_wavg_ln) vs the
     same forward running the three steps separately: identical token schedule and first-layer indices, final
@@ -226,10 +226,18 @@ def test_fused_block_equals_unfused_block_bf16(host_name, monkeypatch):
         model = H["videomae"].VideoMAE(num_frames=8, img_size=64, patch_size=16, embed_dim=64, depth=4, num_heads=1,
                                        num_classes=9)
         patch, frames = tome.patch.videomae, 8
-    else:
+    elif host_name == "vivit":
         model = H["vivit"].ViViT(num_classes=9, image_size=64, num_frames=8, hidden_size=64, num_hidden_layers=4,
                                  num_attention_heads=1, intermediate_size=128)
         patch, frames = tome.patch.vivit, 8
+    elif host_name == "timesformer":
+        model = H["timesformer"].TimeSformer(num_frames=4, img_size=64, patch_size=8, embed_dim=64, depth=4,
+                                             num_heads=1, num_classes=9)
+        patch, frames = tome.patch.timesformer, 4
+    else:
+        model = H["motionformer"].Motionformer(img_size=64, patch_size=8, patch_size_temp=2, temporal_resolution=4,
+                                               embed_dim=64, depth=3, num_heads=1, num_classes=9)
+        patch, frames = tome.patch.motionformer, 8
     model = model.to(DEV).to(torch.bfloat16).eval()
     patch(model)
     clip = torch.rand(3, 3, frames, 64, 64, device=DEV).to(torch.bfloat16)

@@ -473,30 +473,52 @@ extern "C" int tome_merge_wavg_ln(const void *x, int x_dtype, const void *size, 
     return fail(TOME_EINVAL, "tome_merge_wavg_ln: 16-bit tokens only (x=%d size=%d)", x_dtype, size_dtype);
 }
 
-extern "C" int tome_merge_wavg_regrouped(const void *x, int x_dtype, const void *size, int size_dtype, int64_t B,
-                                         int64_t F, int64_t P, int64_t C, int64_t r, int has_cls,
-                                         const int64_t *src_idx, const int64_t *dst_idx, const int64_t *unm_idx,
-                                         const uint8_t *edge_keep, void *x_out, void *size_out,
-                                         tome_stream_t stream) {
-    if (B <= 0 || F <= 0) return fail(TOME_EINVAL, "tome_merge_wavg_regrouped: bad shape");
+static int merge_wavg_regrouped_impl(const char *who, const void *x, int x_dtype, const void *size, int size_dtype,
+                                     int64_t B, int64_t F, int64_t P, int64_t C, int64_t r, int has_cls,
+                                     const int64_t *src_idx, const int64_t *dst_idx, const int64_t *unm_idx,
+                                     const uint8_t *edge_keep, void *x_out, void *size_out, const LnArgs *ln,
+                                     tome_stream_t stream) {
+    if (B <= 0 || F <= 0) return fail(TOME_EINVAL, "%s: bad shape", who);
     const int64_t n = B * F;
-    if (int rc = check_merge_args("tome_merge_wavg_regrouped", x, n, P, C, r, x_out)) return rc;
-    if (!src_idx || !dst_idx || (!unm_idx && (P + 1) / 2 > r) || !size_out)
-        return fail(TOME_EINVAL, "tome_merge_wavg_regrouped: null buffer");
+    if (int rc = check_merge_args(who, x, n, P, C, r, x_out)) return rc;
+    if (!src_idx || !dst_idx || (!unm_idx && (P + 1) / 2 > r) || !size_out) return fail(TOME_EINVAL, "%s: null buffer", who);
     const int cls = has_cls ? 1 : 0;
     const TokLayout lin{cls * C, (cls + P * F) * C, C, F * C, (int)F};
     const TokLayout lout{cls * C, (cls + (P - r) * F) * C, C, F * C, (int)F};
     hipStream_t st = (hipStream_t)stream;
 #define WAVGR(TX, TS)                                                                                         \
     return launch_merge_rows<TX, TS, OP_WAVG>(x, size, n, P, C, r, src_idx, dst_idx, unm_idx, 0, edge_keep, x_out, \
-                                              size_out, st, &lin, &lout, cls ? (int)B : 0)
+                                              size_out, st, &lin, &lout, cls ? (int)B : 0, ln)
     if (x_dtype == TOME_F32 && size_dtype == TOME_F32) WAVGR(float, float);
     if (x_dtype == TOME_BF16 && size_dtype == TOME_BF16) WAVGR(bf16_t, bf16_t);
     if (x_dtype == TOME_BF16 && size_dtype == TOME_F32) WAVGR(bf16_t, float);
     if (x_dtype == TOME_F16 && size_dtype == TOME_F16) WAVGR(f16_t, f16_t);
     if (x_dtype == TOME_F16 && size_dtype == TOME_F32) WAVGR(f16_t, float);
 #undef WAVGR
-    return fail(TOME_EINVAL, "tome_merge_wavg_regrouped: unsupported dtypes x=%d size=%d", x_dtype, size_dtype);
+    return fail(TOME_EINVAL, "%s: unsupported dtypes x=%d size=%d", who, x_dtype, size_dtype);
+}
+
+extern "C" int tome_merge_wavg_regrouped(const void *x, int x_dtype, const void *size, int size_dtype, int64_t B,
+                                         int64_t F, int64_t P, int64_t C, int64_t r, int has_cls,
+                                         const int64_t *src_idx, const int64_t *dst_idx, const int64_t *unm_idx,
+                                         const uint8_t *edge_keep, void *x_out, void *size_out,
+                                         tome_stream_t stream) {
+    return merge_wavg_regrouped_impl("tome_merge_wavg_regrouped", x, x_dtype, size, size_dtype, B, F, P, C, r, has_cls,
+                                     src_idx, dst_idx, unm_idx, edge_keep, x_out, size_out, nullptr, stream);
+}
+
+extern "C" int tome_merge_wavg_regrouped_ln(const void *x, int x_dtype, const void *size, int size_dtype, int64_t B,
+                                            int64_t F, int64_t P, int64_t C, int64_t r, int has_cls,
+                                            const int64_t *src_idx, const int64_t *dst_idx,
+                                            const int64_t *unm_idx, const uint8_t *edge_keep, const void *ln_weight,
+                                            const void *ln_bias, float eps, const void *addend, void *x_out,
+                                            void *y_out, void *size_out, tome_stream_t stream) {
+    if (!y_out || !ln_weight || !ln_bias) return fail(TOME_EINVAL, "tome_merge_wavg_regrouped_ln: null buffer");
+    if (x_dtype == TOME_F32) return fail(TOME_EINVAL, "tome_merge_wavg_regrouped_ln: 16-bit tokens only");
+    if (addend && !aligned16(addend)) return fail(TOME_EINVAL, "tome_merge_wavg_regrouped_ln: addend alignment");
+    const LnArgs ln{ln_weight, ln_bias, y_out, eps, addend};
+    return merge_wavg_regrouped_impl("tome_merge_wavg_regrouped_ln", x, x_dtype, size, size_dtype, B, F, P, C, r,
+                                     has_cls, src_idx, dst_idx, unm_idx, edge_keep, x_out, size_out, &ln, stream);
 }
 
 template <typename TX>

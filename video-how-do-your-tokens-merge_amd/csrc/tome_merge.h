@@ -411,7 +411,62 @@ __global__ __launch_bounds__(256) void k_merge_rows_fast(const TX *__restrict__ 
         if (b < cls_rows) {
             const uint4 *src = reinterpret_cast<const uint4 *>(x + b * lin.outer_stride);
             uint4 *dst = reinterpret_cast<uint4 *>(xout + b * lout.outer_stride);
-            for (int c = lane; c < cpr; c += WAVE) dst[c] = src[c];
+            if (!LN) {
+                for (int c = lane; c < cpr; c += WAVE) dst[c] = src[c];
+            } else {
+                // class-token row: same fused residual and LayerNorm as the merged rows (cpr <= 128 here)
+                const int c0 = lane, c1 = WAVE + lane;
+                const bool a0 = c0 < cpr, a1 = c1 < cpr;
+                Pack<TX, VEC> p0, p1;
+                uint4 r0 = a0 ? src[c0] : uint4{0, 0, 0, 0}, r1 = a1 ? src[c1] : uint4{0, 0, 0, 0};
+                __builtin_memcpy(&p0, &r0, 16);
+                __builtin_memcpy(&p1, &r1, 16);
+                if (ln.addend) {
+                    const uint4 *asrc = reinterpret_cast<const uint4 *>(reinterpret_cast<const TX *>(ln.addend) +
+                                                                        b * lin.outer_stride);
+                    Pack<TX, VEC> q0, q1;
+                    uint4 s0 = a0 ? asrc[c0] : uint4{0, 0, 0, 0}, s1 = a1 ? asrc[c1] : uint4{0, 0, 0, 0};
+                    __builtin_memcpy(&q0, &s0, 16);
+                    __builtin_memcpy(&q1, &s1, 16);
+                    p0 = add_packs<TX, VEC>(p0, q0);
+                    p1 = add_packs<TX, VEC>(p1, q1);
+                    __builtin_memcpy(&r0, &p0, 16);
+                    __builtin_memcpy(&r1, &p1, 16);
+                }
+                if (a0) dst[c0] = r0;
+                if (a1) dst[c1] = r1;
+                float t = 0.0f, u = 0.0f;
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) {
+                    const float v0 = a0 ? to_f32(p0.e[e]) : 0.0f, v1 = a1 ? to_f32(p1.e[e]) : 0.0f;
+                    t += v0 + v1;
+                    u = __fmaf_rn(v0, v0, u);
+                    u = __fmaf_rn(v1, v1, u);
+                }
+                const float fc = (float)C;
+                const float m = wave_sum(t) / fc;
+                const float rs = 1.0f / __builtin_sqrtf(fmaxf(wave_sum(u) / fc - m * m, 0.0f) + ln.eps);
+                const TX *lw = reinterpret_cast<const TX *>(ln.weight), *lb = reinterpret_cast<const TX *>(ln.bias);
+                uint4 *ydst = reinterpret_cast<uint4 *>(reinterpret_cast<TX *>(ln.y) + b * lout.outer_stride);
+                if (a0) {
+                    float w8[VEC], b8[VEC];
+                    load_pack<TX, VEC>(lw + c0 * VEC, w8);
+                    load_pack<TX, VEC>(lb + c0 * VEC, b8);
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) p0.e[e] = from_f32<TX>((to_f32(p0.e[e]) - m) * rs * w8[e] + b8[e]);
+                    __builtin_memcpy(&r0, &p0, 16);
+                    ydst[c0] = r0;
+                }
+                if (a1) {
+                    float w8[VEC], b8[VEC];
+                    load_pack<TX, VEC>(lw + c1 * VEC, w8);
+                    load_pack<TX, VEC>(lb + c1 * VEC, b8);
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) p1.e[e] = from_f32<TX>((to_f32(p1.e[e]) - m) * rs * w8[e] + b8[e]);
+                    __builtin_memcpy(&r1, &p1, 16);
+                    ydst[c1] = r1;
+                }
+            }
         }
         return;
     }

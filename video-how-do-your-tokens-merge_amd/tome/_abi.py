@@ -18,7 +18,7 @@ SYMBOLS = (
     "tome_abi_version", "tome_last_error", "tome_effective_r", "tome_match_workspace_bytes", "tome_match",
     "tome_match_keys",
     "tome_match_scores", "tome_edge_keep", "tome_merge_wavg", "tome_merge_wavg_ln", "tome_merge_wavg_regrouped",
-    "tome_merge", "tome_drop",
+    "tome_merge_wavg_regrouped_ln", "tome_merge", "tome_drop",
     "tome_unmerge",
     "tome_profile_enable", "tome_profile_read",
 )
@@ -70,6 +70,9 @@ def lib() -> ctypes.CDLL:
                                      vp, vp, vp, vp, vp]
     L.tome_merge_wavg_regrouped.restype = i32
     L.tome_merge_wavg_regrouped.argtypes = [vp, i32, vp, i32, i64, i64, i64, i64, i64, i32, vp, vp, vp, vp, vp, vp, vp]
+    L.tome_merge_wavg_regrouped_ln.restype = i32
+    L.tome_merge_wavg_regrouped_ln.argtypes = [vp, i32, vp, i32, i64, i64, i64, i64, i64, i32, vp, vp, vp, vp, vp, vp,
+                                               ctypes.c_float, vp, vp, vp, vp, vp]
     L.tome_merge.restype = i32
     L.tome_merge.argtypes = [vp, i32, i64, i64, i64, i64, vp, vp, vp, i32, i32, vp, vp, vp]
     L.tome_drop.restype = i32
@@ -353,10 +356,12 @@ def merge_wavg_ln(plan: MatchPlan, x: torch.Tensor, size: Optional[torch.Tensor]
 
 
 def merge_wavg_regrouped(plan: MatchPlan, x_full: torch.Tensor, size: Optional[torch.Tensor], frames: int,
-                         has_cls: bool = True):
+                         has_cls: bool = True, ln=None, addend: Optional[torch.Tensor] = None):
     """merge_wavg on the interleaved layout of TimeSformer / Motionformer: x_full [B, has_cls + P*F, C] whose
     token has_cls + p*F + f belongs to group b*F + f; returns x_out [B, has_cls + (P-r)*F, C] and size
-    [B*F, P-r, 1].  Replaces rearrange -> merge_wavg -> rearrange -> cat (timesformer.py:89-107)."""
+    [B*F, P-r, 1].  Replaces rearrange -> merge_wavg -> rearrange -> cat (timesformer.py:89-107).
+    With ln=(weight, bias, eps) it also returns y_out = LayerNorm(x_out) (class-token rows included) between the
+    two, and `addend` (same shape as x_full) is added to the tokens while they are loaded."""
     require_device(x_full, "merge_wavg_regrouped(x)")
     if x_full.dim() != 3:
         raise TomeHipError(f"merge_wavg_regrouped: x must be [B, tokens, C], got {tuple(x_full.shape)}")
@@ -383,13 +388,30 @@ def merge_wavg_regrouped(plan: MatchPlan, x_full: torch.Tensor, size: Optional[t
         sdtype = x_full.dtype
     x_out = torch.empty((B, cls + (P - plan.r) * F, C), dtype=x_full.dtype, device=x_full.device)
     s_out = torch.empty((plan.n, P - plan.r, 1), dtype=sdtype, device=x_full.device)
+    if ln is None:
+        if addend is not None:
+            raise TomeHipError("merge_wavg_regrouped: addend is only fused together with ln")
+        with _on_device(x_full.device):
+            rc = lib().tome_merge_wavg_regrouped(x_full.data_ptr(), xcode, _ptr(size), DTYPES[sdtype], B, F, P, C,
+                                                 plan.r, cls, plan.src_idx.data_ptr(), plan.dst_idx.data_ptr(),
+                                                 plan.unm_idx.data_ptr(), _ptr(plan.edge_keep), x_out.data_ptr(),
+                                                 s_out.data_ptr(), _stream(x_full.device))
+        _check(rc, "tome_merge_wavg_regrouped")
+        return x_out, s_out
+    weight, bias, eps = ln
+    if addend is not None:
+        if addend.shape != x_full.shape or addend.dtype != x_full.dtype or addend.device != x_full.device:
+            raise TomeHipError("merge_wavg_regrouped: addend must match x in shape, dtype and device")
+        addend = addend if addend.is_contiguous() else addend.contiguous()
+    y_out = torch.empty_like(x_out)
     with _on_device(x_full.device):
-        rc = lib().tome_merge_wavg_regrouped(x_full.data_ptr(), xcode, _ptr(size), DTYPES[sdtype], B, F, P, C, plan.r,
-                                             cls, plan.src_idx.data_ptr(), plan.dst_idx.data_ptr(),
-                                             plan.unm_idx.data_ptr(), _ptr(plan.edge_keep), x_out.data_ptr(),
-                                             s_out.data_ptr(), _stream(x_full.device))
-    _check(rc, "tome_merge_wavg_regrouped")
-    return x_out, s_out
+        rc = lib().tome_merge_wavg_regrouped_ln(x_full.data_ptr(), xcode, _ptr(size), DTYPES[sdtype], B, F, P, C,
+                                                plan.r, cls, plan.src_idx.data_ptr(), plan.dst_idx.data_ptr(),
+                                                plan.unm_idx.data_ptr(), _ptr(plan.edge_keep), weight.data_ptr(),
+                                                bias.data_ptr(), float(eps), _ptr(addend), x_out.data_ptr(),
+                                                y_out.data_ptr(), s_out.data_ptr(), _stream(x_full.device))
+    _check(rc, "tome_merge_wavg_regrouped_ln")
+    return x_out, y_out, s_out
 
 
 def merge(plan: MatchPlan, x: torch.Tensor, mode: str) -> torch.Tensor:

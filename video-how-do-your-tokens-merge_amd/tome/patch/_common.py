@@ -151,6 +151,35 @@ def reduce_merge_regrouped(metric, x_full, info, r, frames, hybrid=False):
     return x_out
 
 
+def merge_then_norm_regrouped(metric, x_full, info, norm, unfused_reduce, is_plain_merge: bool, frames: int,
+                              residual=None):
+    """merge_then_norm for the interleaved layouts (TimeSformer '(p t)', Motionformer '(s f)'): x_full is
+    [B, 1 + P*F, C]; `unfused_reduce(x)` is the model's own reduction step (it pops r itself)."""
+    from .. import _abi
+    from ..merge import do_nothing
+    r_list = info["r"]
+    fusable = (_FUSE_LN and is_plain_merge and r_list and r_list[0] > 0 and info["mode"] == "merge"
+               and not info["trace_source"] and _abi.ln_fusable(x_full, norm)
+               and _abi.effective_r((x_full.shape[1] - 1) // frames, r_list[0], False, False) > 0)
+    if not fusable:
+        if residual is not None:
+            x_full = x_full + residual
+        x_full = unfused_reduce(x_full)
+        return x_full, norm(x_full)
+    if residual is not None and (not _FUSE_ADD or residual.dtype != x_full.dtype):
+        x_full = x_full + residual
+        residual = None
+    r = r_list.pop(0)
+    merge, _ = bipartite_soft_matching(metric, r, info["class_token"], info["distill_token"], info["mode"])
+    assert merge is not do_nothing
+    plan = merge.plan
+    x_out, y_out, info["size"] = _abi.merge_wavg_regrouped(plan, x_full, info["size"], frames, has_cls=True,
+                                                          ln=(norm.weight, norm.bias, norm.eps), addend=residual)
+    if info["verbose"]:
+        print(f"Merged {plan.T} to {plan.T - plan.r} tokens")
+    return x_out, y_out
+
+
 def reduce_drop(metric, x, info, r):
     drop = bipartite_soft_matching_drop(metric, r, info["class_token"], info["distill_token"], info["mode"])
     if isinstance(drop, tuple):  # clamped r == 0: the reference returns the do_nothing pair here

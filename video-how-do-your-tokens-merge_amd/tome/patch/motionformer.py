@@ -16,9 +16,11 @@ def _block_forward(self, x, seq_len=196, num_frames=8, approx="none", num_landma
     attn_size = info["size"] if info["prop_attn"] else None
     attn_out, _, metric = self.attn(self.norm1(x), seq_len=seq_len, num_frames=num_frames, approx=approx,
                                     num_landmarks=num_landmarks, size=attn_size)
-    x = x + self.drop_path(attn_out)
-    x = self.reduction_function(metric, x, info, num_frames)
-    return x + self.drop_path(self.mlp(self.norm2(x)))
+    # x = x + attn; merge per group; norm2 -- one kernel when the layer merges 16-bit tokens
+    x, y = C.merge_then_norm_regrouped(
+        metric, x, info, self.norm2, lambda z: self.reduction_function(metric, z, info, num_frames),
+        self.reduction_function is motionformer_merge, num_frames, residual=self.drop_path(attn_out))
+    return x + self.drop_path(self.mlp(y))
 
 
 def qkv_attn(q, k, v):

@@ -31,9 +31,13 @@ def _block_forward(self, x, B, T, W):
     rs = self.drop_path(rs)
     cls_new = rs[:, 0, :].reshape(B, T, m).mean(1, keepdim=True)  # class token averaged over frames
     rs = rs[:, 1:, :].reshape(B, T, P, m).transpose(1, 2).reshape(B, P * T, m)
-    x = torch.cat((cls0, xt), 1) + torch.cat((cls_new, rs), 1)
-    x = self.reduction_function(metric, x, info, B, T, P)
-    return x + self.drop_path(self.mlp(self.norm2(x)))
+    # x = cat(cls0, xt) + cat(cls_new, rs); merge per frame; norm2 -- one kernel when the layer merges 16-bit
+    # tokens (tome_merge_wavg_regrouped_ln), the reference's steps otherwise
+    x, y = C.merge_then_norm_regrouped(
+        metric, torch.cat((cls0, xt), 1), info, self.norm2,
+        lambda z: self.reduction_function(metric, z, info, B, T, P), self.reduction_function is timesformer_merge, T,
+        residual=torch.cat((cls_new, rs), 1))
+    return x + self.drop_path(self.mlp(y))
 
 
 def _attention_forward(self, x, size: torch.Tensor = None):
