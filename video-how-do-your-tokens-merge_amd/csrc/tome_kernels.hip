@@ -145,6 +145,7 @@ static int launch_select(const MatchWs &w, int nparts, bool nan_flags, int64_t n
     dim3 grid((T1 + 63) / 64, (unsigned)n);
     const int quarter = (((T1 + 3) >> 2) + 1) & ~1;
     const size_t lds = sizeof(unsigned long long) * (size_t)(4 * quarter);
+    if (lds > 160 * 1024) return fail(TOME_EINVAL, "sequences of more than ~40000 tokens do not fit the ranking kernel's LDS");
     hipLaunchKernelGGL(k_rank_select, grid, dim3(256), lds, st, w.part_max, w.part_idx, nparts, (int)n, T1,
                        (int)(T / 2), nan_flags ? w.badA : nullptr, nan_flags ? w.badB : nullptr, (int)re, class_token,
                        distill_token, src_idx, dst_idx, unm_idx, node_max, w.rank, row_map);

@@ -100,12 +100,13 @@ def _make_merge_pair(plan: _abi.MatchPlan) -> Tuple[Callable, Callable]:
     r, distill_token = plan.r, plan.distill_token
 
     def merge(x: torch.Tensor, mode="mean") -> torch.Tensor:
-        assert src_idx.shape[1] == r and dst_idx.shape[1] == r and unm_idx.shape[0] == x.shape[0]
-        assert distill_token == plan.distill_token
+        # the index tensors are closure variables on purpose (same names as the reference's closure, so
+        # `merge.__closure__` introspection keeps working); the kernels read them through `plan`
+        _closure = (unm_idx, src_idx, dst_idx, r, distill_token)  # noqa: F841
         return _abi.merge(plan, x, mode)
 
     def unmerge(x: torch.Tensor) -> torch.Tensor:
-        assert src_idx.shape[1] == r and dst_idx.shape[1] == r and unm_idx.shape[0] == x.shape[0]
+        _closure = (unm_idx, src_idx, dst_idx, r)  # noqa: F841
         return _abi.unmerge(plan, x)
 
     merge.plan = plan
@@ -131,8 +132,7 @@ def bipartite_soft_matching_drop(
     r, distill_token = plan.r, plan.distill_token
 
     def drop(x: torch.Tensor) -> torch.Tensor:
-        assert und_idx.shape[0] == x.shape[0] and src_idx.shape[1] == r
-        assert distill_token == plan.distill_token
+        _closure = (und_idx, src_idx, r, distill_token)  # noqa: F841  (closure variables as in the reference)
         return _abi.drop(plan, x)
 
     drop.plan = plan
