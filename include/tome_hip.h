@@ -157,6 +157,16 @@ int tome_merge_wavg_regrouped_ln(const void *x, int x_dtype, const void *size, i
                                  const void *addend, void *x_out, void *y_out, void *size_out,
                                  tome_stream_t stream);
 
+/*
+ * tome_add_layernorm  <-  the second residual of the patched block and the LayerNorm that consumes it:
+ *     x = x + self.drop_path(self.mlp(self.norm2(x)))      (tome/patch/videomae.py:29)
+ *     ... next ToMeBlock.forward: self.norm1(x)            (tome/patch/videomae.py:19)
+ * x_out = round(x + addend), y_out = LayerNorm(x_out), both [rows, C] of `dtype` (16-bit, C <= 1024, C % 8 == 0).
+ */
+int tome_add_layernorm(const void *x, const void *addend, int dtype, int64_t rows, int64_t C,
+                       const void *ln_weight, const void *ln_bias, float eps, void *x_out, void *y_out,
+                       tome_stream_t stream);
+
 /* tome_merge  <-  merge(x, mode) closure (merge.py:75-85; hybrid :313-334 when edge_keep). */
 int tome_merge(const void *x, int dtype, int64_t n, int64_t T, int64_t C, int64_t r,
                const int64_t *src_idx, const int64_t *dst_idx, const int64_t *unm_idx,

@@ -552,3 +552,19 @@ def test_merge_wavg_regrouped_ln(B, F, P, C, r, dtype):
     ref = torch.nn.functional.layer_norm(want_x.float(), (C,), w.float(), b.float(), 1e-6)
     tol = 2 ** -7 if dtype == torch.bfloat16 else 2 ** -10
     assert float(((got_y.float() - ref).abs() / ref.abs().clamp(min=1.0)).max()) <= tol
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.bfloat16, 2 ** -7), (torch.float16, 2 ** -10)])
+@pytest.mark.parametrize("shape", [(3, 197, 768), (5, 64), (2, 1001, 1024), (7, 8)])
+def test_add_layernorm(shape, dtype, tol):
+    """tome_add_layernorm: x_out == torch's x + a bit for bit, y_out == LayerNorm(x_out) within one epsilon."""
+    from tome import _abi
+    C = shape[-1]
+    x = dev(synth.normal_like(shape, 11 + C), dtype)
+    a = dev(0.5 * synth.normal_like(shape, 12 + C), dtype)
+    w = dev(1.0 + 0.1 * synth.normal_like((C,), 13), dtype)
+    b = dev(0.1 * synth.normal_like((C,), 14), dtype)
+    xo, yo = _abi.add_layernorm(x, a, w, b, 1e-6)
+    assert torch.equal(xo, x + a)
+    ref = torch.nn.functional.layer_norm((x + a).float(), (C,), w.float(), b.float(), 1e-6)
+    assert float(((yo.float() - ref).abs() / ref.abs().clamp(min=1.0)).max()) <= tol

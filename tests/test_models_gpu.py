@@ -245,6 +245,7 @@ def test_fused_block_equals_unfused_block_bf16(host_name, monkeypatch):
     for fused in (True, False):
         monkeypatch.setattr(_common, "_FUSE_LN", fused)
         monkeypatch.setattr(_common, "_FUSE_ADD", fused)
+        monkeypatch.setattr(_common, "_FUSE_NEXT", fused)
         out, plans = _trace(tome, model, clip, 5)
         outs[fused] = (out.float(), plans, model._tome_info["size"].float().clone())
     (o1, p1, s1), (o0, p0, s0) = outs[True], outs[False]

@@ -522,6 +522,31 @@ extern "C" int tome_merge_wavg_regrouped_ln(const void *x, int x_dtype, const vo
                                      has_cls, src_idx, dst_idx, unm_idx, edge_keep, x_out, size_out, &ln, stream);
 }
 
+extern "C" int tome_add_layernorm(const void *x, const void *addend, int dtype, int64_t rows, int64_t C,
+                                  const void *ln_weight, const void *ln_bias, float eps, void *x_out, void *y_out,
+                                  tome_stream_t stream) {
+    if (!x || !addend || !ln_weight || !ln_bias || !x_out || !y_out || rows <= 0 || C <= 0)
+        return fail(TOME_EINVAL, "tome_add_layernorm: bad shape/pointer");
+    if (dtype != TOME_BF16 && dtype != TOME_F16) return fail(TOME_EINVAL, "tome_add_layernorm: 16-bit tokens only");
+    const int64_t cpr = C / 8;
+    if (C % 8 || cpr > 2 * WAVE || !aligned16(x) || !aligned16(addend) || !aligned16(x_out) || !aligned16(y_out) ||
+        !aligned16(ln_weight) || !aligned16(ln_bias))
+        return fail(TOME_EINVAL, "tome_add_layernorm: C %% 8 == 0, C <= 1024 and 16-byte aligned buffers required");
+    int R = (int)((FAST_NIT * WAVE) / cpr);
+    if (R > FAST_MAXR) R = FAST_MAXR;
+    const int64_t waves = (rows + R - 1) / R;
+    const LnArgs ln{ln_weight, ln_bias, y_out, eps, nullptr};
+    const dim3 grid((unsigned)((waves + 3) / 4));
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == TOME_BF16)
+        hipLaunchKernelGGL((k_add_ln_rows<bf16_t, FAST_NIT>), grid, dim3(256), 0, st, (const bf16_t *)x,
+                           (const bf16_t *)addend, rows, (int)C, R, (int)cpr, ln, (bf16_t *)x_out);
+    else
+        hipLaunchKernelGGL((k_add_ln_rows<f16_t, FAST_NIT>), grid, dim3(256), 0, st, (const f16_t *)x,
+                           (const f16_t *)addend, rows, (int)C, R, (int)cpr, ln, (f16_t *)x_out);
+    return check_launch("k_add_ln_rows");
+}
+
 template <typename TX>
 static int merge_mode_dispatch(int mode, const void *x, int64_t n, int64_t T, int64_t C, int64_t r,
                                const int64_t *src, const int64_t *dst, const int64_t *unm, int distill,

@@ -678,6 +678,88 @@ __global__ __launch_bounds__(256) void k_merge_rows_fast(const TX *__restrict__ 
     }
 }
 
+// k_add_ln_rows: the other residual of the patched block, fused with the LayerNorm that reads its result:
+//     x = x + mlp(norm2(x))            (tome/patch/videomae.py:29, end of ToMeBlock.forward)
+//     ... next block: self.norm1(x)    (tome/patch/videomae.py:19)
+// x' = round(x + a) and y = LayerNorm(x') in one pass (same arithmetic as the LN tail of k_merge_rows_fast).
+// A wave owns R consecutive rows, NIT 16-byte chunks per lane, everything loaded before use.
+template <typename TX, int NIT>
+__global__ __launch_bounds__(256) void k_add_ln_rows(const TX *__restrict__ x, const TX *__restrict__ a,
+                                                     int64_t rows, int C, int R, int cpr, LnArgs ln,
+                                                     TX *__restrict__ xout) {
+    constexpr int VEC = 16 / sizeof(TX);
+    const int lane = threadIdx.x & 63;
+    const int64_t w = (int64_t)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t row0 = w * R;
+    if (row0 >= rows) return;
+    const int nrow = (int)((rows - row0) < R ? (rows - row0) : R);
+    const int total = nrow * cpr;
+    const uint4 *xs = reinterpret_cast<const uint4 *>(x + row0 * C), *as = reinterpret_cast<const uint4 *>(a + row0 * C);
+    uint4 raw[NIT], rawa[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int q = it * WAVE + lane;
+        if (q < total) {
+            raw[it] = xs[q];
+            rawa[it] = as[q];
+        }
+    }
+    uint4 *xo = reinterpret_cast<uint4 *>(xout + row0 * C);
+    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f, q0 = 0.0f, q1 = 0.0f, q2 = 0.0f, q3 = 0.0f;
+    int rowof[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int q = it * WAVE + lane;
+        const int rr = (q >= cpr) + (q >= 2 * cpr) + (q >= 3 * cpr);
+        rowof[it] = q < total ? rr : -1;
+        if (q >= total) continue;
+        Pack<TX, VEC> px, pa;
+        __builtin_memcpy(&px, &raw[it], 16);
+        __builtin_memcpy(&pa, &rawa[it], 16);
+        const Pack<TX, VEC> ps = add_packs<TX, VEC>(px, pa);
+        __builtin_memcpy(&raw[it], &ps, 16);
+        xo[q] = raw[it];
+        float t = 0.0f, u = 0.0f;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            const float v = to_f32(ps.e[e]);
+            t += v;
+            u = __fmaf_rn(v, v, u);
+        }
+        s0 += rr == 0 ? t : 0.0f; q0 += rr == 0 ? u : 0.0f;
+        s1 += rr == 1 ? t : 0.0f; q1 += rr == 1 ? u : 0.0f;
+        s2 += rr == 2 ? t : 0.0f; q2 += rr == 2 ? u : 0.0f;
+        s3 += rr == 3 ? t : 0.0f; q3 += rr == 3 ? u : 0.0f;
+    }
+    const float fc = (float)C;
+    const float m0 = wave_sum(s0) / fc, m1 = wave_sum(s1) / fc, m2 = wave_sum(s2) / fc, m3 = wave_sum(s3) / fc;
+    const float r0 = 1.0f / __builtin_sqrtf(fmaxf(wave_sum(q0) / fc - m0 * m0, 0.0f) + ln.eps),
+                r1 = 1.0f / __builtin_sqrtf(fmaxf(wave_sum(q1) / fc - m1 * m1, 0.0f) + ln.eps),
+                r2 = 1.0f / __builtin_sqrtf(fmaxf(wave_sum(q2) / fc - m2 * m2, 0.0f) + ln.eps),
+                r3 = 1.0f / __builtin_sqrtf(fmaxf(wave_sum(q3) / fc - m3 * m3, 0.0f) + ln.eps);
+    const TX *lw = reinterpret_cast<const TX *>(ln.weight), *lb = reinterpret_cast<const TX *>(ln.bias);
+    uint4 *yo = reinterpret_cast<uint4 *>(reinterpret_cast<TX *>(ln.y) + row0 * C);
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int rr = rowof[it];
+        if (rr < 0) continue;
+        const int q = it * WAVE + lane;
+        const int cc = q - rr * cpr;
+        const float m = rr == 0 ? m0 : (rr == 1 ? m1 : (rr == 2 ? m2 : m3));
+        const float rs = rr == 0 ? r0 : (rr == 1 ? r1 : (rr == 2 ? r2 : r3));
+        Pack<TX, VEC> pk;
+        __builtin_memcpy(&pk, &raw[it], 16);
+        float w8[VEC], b8[VEC];
+        load_pack<TX, VEC>(lw + cc * VEC, w8);
+        load_pack<TX, VEC>(lb + cc * VEC, b8);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) pk.e[e] = from_f32<TX>((to_f32(pk.e[e]) - m) * rs * w8[e] + b8[e]);
+        uint4 yv;
+        __builtin_memcpy(&yv, &pk, 16);
+        yo[q] = yv;
+    }
+}
+
 // k_unmerge_rows: merge.py:87-100 as a scatter from the merged sequence: one wave per INPUT row; a
 // destination row also lands on every even slot that was merged into it.  src and unm partition the
 // even slots, so every output row is written exactly once and no zero fill is needed.

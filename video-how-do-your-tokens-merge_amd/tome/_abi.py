@@ -18,7 +18,7 @@ SYMBOLS = (
     "tome_abi_version", "tome_last_error", "tome_effective_r", "tome_match_workspace_bytes", "tome_match",
     "tome_match_keys",
     "tome_match_scores", "tome_edge_keep", "tome_merge_wavg", "tome_merge_wavg_ln", "tome_merge_wavg_regrouped",
-    "tome_merge_wavg_regrouped_ln", "tome_merge", "tome_drop",
+    "tome_merge_wavg_regrouped_ln", "tome_add_layernorm", "tome_merge", "tome_drop",
     "tome_unmerge",
     "tome_profile_enable", "tome_profile_read",
 )
@@ -73,6 +73,8 @@ def lib() -> ctypes.CDLL:
     L.tome_merge_wavg_regrouped_ln.restype = i32
     L.tome_merge_wavg_regrouped_ln.argtypes = [vp, i32, vp, i32, i64, i64, i64, i64, i64, i32, vp, vp, vp, vp, vp, vp,
                                                ctypes.c_float, vp, vp, vp, vp, vp]
+    L.tome_add_layernorm.restype = i32
+    L.tome_add_layernorm.argtypes = [vp, vp, i32, i64, i64, vp, vp, ctypes.c_float, vp, vp, vp]
     L.tome_merge.restype = i32
     L.tome_merge.argtypes = [vp, i32, i64, i64, i64, i64, vp, vp, vp, i32, i32, vp, vp, vp]
     L.tome_drop.restype = i32
@@ -353,6 +355,24 @@ def merge_wavg_ln(plan: MatchPlan, x: torch.Tensor, size: Optional[torch.Tensor]
                                       _stream(x.device))
     _check(rc, "tome_merge_wavg_ln")
     return x_out, y_out, s_out
+
+
+def add_layernorm(x: torch.Tensor, addend: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, eps: float):
+    """(x + addend, LayerNorm(x + addend)) in one launch, for 16-bit [..., C] tensors (C <= 1024, C % 8 == 0)."""
+    require_device(x, "add_layernorm(x)")
+    if addend.shape != x.shape or addend.dtype != x.dtype or addend.device != x.device:
+        raise TomeHipError("add_layernorm: addend must match x in shape, dtype and device")
+    x = x if x.is_contiguous() else x.contiguous()
+    addend = addend if addend.is_contiguous() else addend.contiguous()
+    C = x.shape[-1]
+    x_out = torch.empty_like(x)
+    y_out = torch.empty_like(x)
+    with _on_device(x.device):
+        rc = lib().tome_add_layernorm(x.data_ptr(), addend.data_ptr(), dtype_code(x, "x"), x.numel() // C, C,
+                                      weight.data_ptr(), bias.data_ptr(), float(eps), x_out.data_ptr(),
+                                      y_out.data_ptr(), _stream(x.device))
+    _check(rc, "tome_add_layernorm")
+    return x_out, y_out
 
 
 def merge_wavg_regrouped(plan: MatchPlan, x_full: torch.Tensor, size: Optional[torch.Tensor], frames: int,

@@ -18,6 +18,7 @@ from ..utils import parse_r
 _SUBCLASSES: Dict[Tuple[type, str], type] = {}
 _FUSE_LN = os.environ.get("TOME_FUSE_LN", "1") != "0"  # measurement switch: 0 = merge and LayerNorm as two steps
 _FUSE_ADD = os.environ.get("TOME_FUSE_ADD", "1") != "0"  # measurement switch: 0 = residual add as its own pass
+_FUSE_NEXT = os.environ.get("TOME_FUSE_NEXT", "1") != "0"  # 0 = second residual and the next block's norm1 separate
 
 
 def swizzle(module: torch.nn.Module, tag: str, methods: dict) -> None:
@@ -66,6 +67,7 @@ def wrap_model_forward(model_wrapper: torch.nn.Module, blocks_of: Callable) -> N
         self._tome_info["r"] = parse_r(len(blocks_of(self)), self.r)
         self._tome_info["size"] = None
         self._tome_info["source"] = None
+        self._tome_info.pop("_prenorm", None)
         return super(sub, self).forward(*args, **kwdargs)
 
     sub = type("ToMeVisionTransformer", (base,), {"forward": forward, "_tome_tag": "ToMeVisionTransformer"})
@@ -92,6 +94,39 @@ def reduce_merge(metric, x, info, r):
     if info["verbose"]:
         print(f"Merged {before} to {x.size(1)} tokens")
     return x
+
+
+def link_next_norms(blocks, norm_attr: str, tag: str = "ToMeBlock") -> None:
+    """Tell every patched block which LayerNorm reads its output (the next block's first norm), so the block's
+    last residual add can hand that norm's result over (finish_block / first_norm).  Stored without registering
+    the norm as a submodule of the previous block."""
+    blocks = list(blocks)
+    for cur, nxt in zip(blocks, blocks[1:]):
+        target = getattr(nxt, norm_attr, None) if has_tag(nxt, tag) and nxt is not cur else None
+        object.__setattr__(cur, "_tome_next_norm", target)
+    if blocks:
+        object.__setattr__(blocks[-1], "_tome_next_norm", None)
+
+
+def first_norm(block, x, info, norm):
+    """norm(x) at the top of a block -- taken from the previous block's fused add+LayerNorm when it left one
+    for exactly this tensor."""
+    pre = info.pop("_prenorm", None)
+    if pre is not None and pre[0] is x and pre[2] is norm:
+        return pre[1]
+    return norm(x)
+
+
+def finish_block(block, x, residual, info):
+    """x + residual at the end of a block; when the next block's first LayerNorm is known and the tokens are
+    16-bit, tome_add_layernorm produces the sum and that norm's output together."""
+    from .. import _abi
+    nxt = getattr(block, "_tome_next_norm", None)
+    if _FUSE_NEXT and nxt is not None and residual.dtype == x.dtype and _abi.ln_fusable(x, nxt):
+        x, h = _abi.add_layernorm(x, residual, nxt.weight, nxt.bias, nxt.eps)
+        info["_prenorm"] = (x, h, nxt)
+        return x
+    return x + residual
 
 
 def merge_then_norm(metric, x, info, norm, reduction_function, plain_merge_fn, residual=None):

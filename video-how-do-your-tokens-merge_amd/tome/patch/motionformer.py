@@ -14,13 +14,13 @@ def _block_forward(self, x, seq_len=196, num_frames=8, approx="none", num_landma
     """ToMeBlock.forward (motionformer.py:15-30)."""
     info = self._tome_info
     attn_size = info["size"] if info["prop_attn"] else None
-    attn_out, _, metric = self.attn(self.norm1(x), seq_len=seq_len, num_frames=num_frames, approx=approx,
-                                    num_landmarks=num_landmarks, size=attn_size)
+    attn_out, _, metric = self.attn(C.first_norm(self, x, info, self.norm1), seq_len=seq_len, num_frames=num_frames,
+                                    approx=approx, num_landmarks=num_landmarks, size=attn_size)
     # x = x + attn; merge per group; norm2 -- one kernel when the layer merges 16-bit tokens
     x, y = C.merge_then_norm_regrouped(
         metric, x, info, self.norm2, lambda z: self.reduction_function(metric, z, info, num_frames),
         self.reduction_function is motionformer_merge, num_frames, residual=self.drop_path(attn_out))
-    return x + self.drop_path(self.mlp(y))
+    return C.finish_block(self, x, self.drop_path(self.mlp(y)), info)
 
 
 def qkv_attn(q, k, v):
@@ -126,3 +126,4 @@ def apply_patch(model, trace_source: bool = False, prop_attn: bool = True, mode:
             module.reduction_function = reduction_function
         elif _is_trajectory_attention(module):
             C.swizzle(module, "ToMeTrajectoryAttention", {"forward": _trajectory_forward})
+    C.link_next_norms(model.blocks, "norm1")

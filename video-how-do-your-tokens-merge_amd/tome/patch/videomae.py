@@ -19,7 +19,7 @@ def _block_forward(self, x):
     """ToMeBlock.forward (videomae.py:14-30)."""
     info = self._tome_info
     attn_size = info["size"] if info["prop_attn"] else None
-    attn, metric = self.attn(self.norm1(x), attn_size, info["head_aggregation"])
+    attn, metric = self.attn(C.first_norm(self, x, info, self.norm1), attn_size, info["head_aggregation"])
     if self.gamma_1 is not None:
         attn = self.gamma_1 * attn
     # x = x + attn; x = merge(x); y = norm2(x) -- one kernel when the layer merges 16-bit tokens
@@ -29,7 +29,8 @@ def _block_forward(self, x):
     y = self.mlp(y)
     if self.gamma_2 is not None:
         y = self.gamma_2 * y
-    return x + self.drop_path(y)
+    # x + mlp(...), and the next block's norm1 of it in the same pass when that is possible
+    return C.finish_block(self, x, self.drop_path(y), info)
 
 
 def _duplicate_block_forward(self, x):
@@ -110,3 +111,4 @@ def apply_patch(model_wrapper, trace_source: bool = False, prop_attn: bool = Fal
             module.reduction_function = reduction_function
         elif _is_attention(module):
             C.swizzle(module, "ToMeAttention", {"forward": _attention_forward})
+    C.link_next_norms(model.blocks, "norm1")

@@ -17,15 +17,17 @@ def _layer_forward(self, hidden_states, head_mask=None, output_attentions=False)
     """ToMeVivitLayer.forward (vivit.py:18-47)."""
     info = self._tome_info
     attn_size = info["size"] if info["prop_attn"] else None
-    outs = self.attention(self.layernorm_before(hidden_states), attn_size, info["head_aggregation"], head_mask,
-                          output_attentions=output_attentions)
+    outs = self.attention(C.first_norm(self, hidden_states, info, self.layernorm_before), attn_size,
+                          info["head_aggregation"], head_mask, output_attentions=output_attentions)
     attention_output, metric, rest = outs[0], outs[1], outs[2:]
     # first residual, merge, layernorm_after -- one kernel when the layer merges 16-bit tokens
     # (tome_merge_wavg_ln with the attention output as addend), the three steps of the reference otherwise
     hidden_states, normed = C.merge_then_norm(metric, hidden_states, info, self.layernorm_after,
                                               self.reduction_function, vivit_merge, residual=attention_output)
     layer_output = self.intermediate(normed)
-    layer_output = self.output(layer_output, hidden_states)  # second residual inside
+    # VivitOutput = dense -> dropout -> + hidden_states; the add is done by finish_block so that the next layer's
+    # layernorm_before can come out of the same pass
+    layer_output = C.finish_block(self, hidden_states, self.output.dropout(self.output.dense(layer_output)), info)
     return (layer_output,) + rest
 
 
@@ -134,3 +136,4 @@ def apply_patch(model_wrapper, trace_source: bool = False, prop_attn: bool = Tru
             C.swizzle(module, "ToMeVivitAttention", {"forward": _attention_forward})
         elif _is_self_attention(module):
             C.swizzle(module, "ToMeVivitSelfAttention", {"forward": _self_attention_forward})
+    C.link_next_norms(model.encoder.layer, "layernorm_before", tag="ToMeVivitLayer")
