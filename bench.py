@@ -78,6 +78,7 @@ def measure_kernels(batch: int, t0: int, r: int, dev, reps: int = 10):
         "k_scores_rowmax": {"ms": 0.0, "bytes": 0, "flops": 0, "launches": 0},
         "k_rank_select": {"ms": 0.0, "bytes": 0, "flops": 0, "launches": 0},
         "k_merge_rows": {"ms": 0.0, "bytes": 0, "flops": 0, "launches": 0},
+        "k_add_ln_rows": {"ms": 0.0, "bytes": 0, "flops": 0, "launches": 0},
     }
     st = torch.cuda.current_stream(dev).cuda_stream
     # the tokens and their sizes evolve through the 12 layers exactly as in a forward (most sizes stay 1,
@@ -136,6 +137,24 @@ def measure_kernels(batch: int, t0: int, r: int, dev, reps: int = 10):
         # SURVEY 8d (read x and size once, write x' and size' once; bf16 tokens and sizes) + the fused residual's
         # second input and the fused norm2's own output y = LayerNorm(x') (its input never leaves the kernel)
         stats["k_merge_rows"]["bytes"] += batch * (2 * t * EMBED * 2 + t * 2 + 2 * (t - re) * EMBED * 2 + (t - re) * 2)
+        # --- second residual + next block's norm1 (tome_add_layernorm) on the merged tokens
+        if len(stats["k_add_ln_rows"]) and t != sched[-1][0]:
+            x2 = torch.empty_like(x_out)
+
+            def launch2():
+                rc = L.tome_add_layernorm(x_out.data_ptr(), y_out.data_ptr(), 1, batch * (t - re), EMBED, ln_w.data_ptr(),
+                                          ln_b.data_ptr(), 1e-6, x2.data_ptr(), y_out.data_ptr(), st)
+                assert rc == 0
+            for _ in range(2):
+                launch2()
+            e0.record()
+            for _ in range(reps):
+                launch2()
+            e1.record()
+            e1.synchronize()
+            stats["k_add_ln_rows"]["ms"] += e0.elapsed_time(e1) / reps
+            stats["k_add_ln_rows"]["launches"] += 1
+            stats["k_add_ln_rows"]["bytes"] += batch * (t - re) * EMBED * 2 * 4  # read x, a; write x', y
         x, size = x_out, s_out
     return stats
 

@@ -20,7 +20,8 @@ def load(d):
     for row in csv.DictReader(open(f)):
         name = row["Kernel_Name"]
         key = None
-        for k in ("k_merge_rows", "k_scores_rowmax", "k_unit_rows", "k_unit_rows_heads", "k_rank_select", "bfloat16_copy_kernel"):
+        for k in ("k_merge_rows", "k_scores_rowmax", "k_unit_rows", "k_unit_rows_heads", "k_rank_select", "k_add_ln_rows",
+                  "bfloat16_copy_kernel"):
             if k in name:
                 key = k
         if key is None:
