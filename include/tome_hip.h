@@ -39,7 +39,7 @@ enum tome_status {
     TOME_ELAUNCH = 3     /* HIP reported a launch error (text in tome_last_error()) */
 };
 
-#define TOME_ABI_VERSION 1
+#define TOME_ABI_VERSION 2
 
 int tome_abi_version(void);
 
@@ -108,13 +108,18 @@ int tome_edge_keep(const float *node_max, const int64_t *src_idx, int64_t n, int
  * x [n,T,C] of x_dtype, contiguous.  size: NULL (ones, :362-363) or [n,T] of size_dtype.
  * x_out [n,T-r,C] of x_dtype, size_out [n,T-r] of size_dtype.  r is the clamped r (> 0).
  * edge_keep: NULL, or the hybrid flags (merge.py:326).
+ * log_size_out: NULL, or [n,T-r] of size_dtype receiving log(size_out) -- the proportional-attention bias the
+ * next block adds to its logits (`size.log()`, tome/patch/videomae.py:62-63, timesformer.py:73-74,
+ * motionformer.py:107-111, vivit.py:103-104): fp32 log of the stored size, rounded to size_dtype.  All four
+ * tome_merge_wavg* entries take it.
  * Arithmetic in fp32 (products, then sequential adds from the destination's own term in src_idx
  * order, then one division); results rounded once to the output dtype.
  */
 int tome_merge_wavg(const void *x, int x_dtype, const void *size, int size_dtype, int64_t n,
                     int64_t T, int64_t C, int64_t r, const int64_t *src_idx,
                     const int64_t *dst_idx, const int64_t *unm_idx, int distill_token,
-                    const uint8_t *edge_keep, void *x_out, void *size_out, tome_stream_t stream);
+                    const uint8_t *edge_keep, void *x_out, void *size_out, void *log_size_out,
+                    tome_stream_t stream);
 
 /*
  * tome_merge_wavg_ln  <-  merge_wavg followed by the block's second LayerNorm:
@@ -130,7 +135,7 @@ int tome_merge_wavg_ln(const void *x, int x_dtype, const void *size, int size_dt
                        int64_t C, int64_t r, const int64_t *src_idx, const int64_t *dst_idx,
                        const int64_t *unm_idx, int distill_token, const uint8_t *edge_keep,
                        const void *ln_weight, const void *ln_bias, float eps, const void *addend, void *x_out,
-                       void *y_out, void *size_out, tome_stream_t stream);
+                       void *y_out, void *size_out, void *log_size_out, tome_stream_t stream);
 
 /*
  * tome_merge_wavg_regrouped  <-  the rearrange / merge_wavg / rearrange / cat sequence of
@@ -145,7 +150,8 @@ int tome_merge_wavg_ln(const void *x, int x_dtype, const void *size, int size_dt
 int tome_merge_wavg_regrouped(const void *x, int x_dtype, const void *size, int size_dtype, int64_t B,
                               int64_t F, int64_t P, int64_t C, int64_t r, int has_cls,
                               const int64_t *src_idx, const int64_t *dst_idx, const int64_t *unm_idx,
-                              const uint8_t *edge_keep, void *x_out, void *size_out, tome_stream_t stream);
+                              const uint8_t *edge_keep, void *x_out, void *size_out, void *log_size_out,
+                              tome_stream_t stream);
 
 /* tome_merge_wavg_regrouped with the residual add in front and the block's norm2 behind it fused in, as
  * tome_merge_wavg_ln does for the plain layout (timesformer.py:52-56, motionformer.py:24-29).  The class-token
@@ -155,7 +161,7 @@ int tome_merge_wavg_regrouped_ln(const void *x, int x_dtype, const void *size, i
                                  const int64_t *src_idx, const int64_t *dst_idx, const int64_t *unm_idx,
                                  const uint8_t *edge_keep, const void *ln_weight, const void *ln_bias, float eps,
                                  const void *addend, void *x_out, void *y_out, void *size_out,
-                                 tome_stream_t stream);
+                                 void *log_size_out, tome_stream_t stream);
 
 /*
  * tome_add_layernorm  <-  the second residual of the patched block and the LayerNorm that consumes it:

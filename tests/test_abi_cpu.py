@@ -58,7 +58,7 @@ def test_argument_validation_without_gpu():
     rc = L.tome_match(None, 0, 2, 16, 8, 128, 8, 4, 0, 0, None, None, None, None, None, None, 0, None)
     assert rc == 1
     buf = ctypes.create_string_buffer(64)
-    rc = L.tome_merge_wavg(buf, 7, None, 0, 1, 8, 4, 9, buf, buf, buf, 0, None, buf, buf, None)
+    rc = L.tome_merge_wavg(buf, 7, None, 0, 1, 8, 4, 9, buf, buf, buf, 0, None, buf, buf, None, None)
     assert rc == 1  # r outside (0, T/2]
 
 

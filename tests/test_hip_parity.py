@@ -568,3 +568,77 @@ def test_add_layernorm(shape, dtype, tol):
     assert torch.equal(xo, x + a)
     ref = torch.nn.functional.layer_norm((x + a).float(), (C,), w.float(), b.float(), 1e-6)
     assert float(((yo.float() - ref).abs() / ref.abs().clamp(min=1.0)).max()) <= tol
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("n,T,C,r,cls", [(3, 197, 768, 16, True), (2, 64, 24, 30, False), (2, 392, 768, 150, False),
+                                         (2, 50, 7, 9, False)])
+def test_log_size_emitted_by_merge(n, T, C, r, cls, dtype):
+    """Every tome_merge_wavg* entry can emit log(size') for the next block's proportional-attention bias
+    (`size.log()`, videomae.py:62-63): the emitted tensor equals torch's `.log()` of the emitted size bit for
+    bit (fp32 log rounded to the size dtype), and equals the CPU oracle's size logged in fp32 within 1 ulp of
+    fp32 / exactly after rounding to a 16-bit format.  The other outputs do not change."""
+    from tome import _abi
+    tm = _tome()
+    seed = 13 * n + T + C
+    metric = dev(synth.normal_like((n, T, 64), seed))
+    x = dev(synth.normal_like((n, T, C), seed + 1), dtype)
+    size = dev(synth.small_ints((n, T, 1), seed + 2, 1, 40), dtype)
+    merge, _ = tm.bipartite_soft_matching(metric, r, cls)
+    for s_in in (None, size):
+        want_x, want_s = tm.merge_wavg(merge, x, s_in)
+        assert getattr(want_s, "_tome_log", None) is None
+        got_x, got_s = tm.merge_wavg(merge, x, s_in, log_size=True)
+        assert torch.equal(got_x, want_x) and torch.equal(got_s, want_s)
+        log = got_s._tome_log
+        assert log.shape == got_s.shape and log.dtype == got_s.dtype
+        assert torch.equal(log, got_s.log())
+        assert _abi.log_of_size(got_s) is log and torch.equal(_abi.log_of_size(want_s), log)
+        o_plan = oracle.match(metric, r, cls)
+        _, o_s = oracle.merge_wavg(o_plan, x, None if s_in is None else s_in)
+        o_st = torch.from_numpy(o_s).to(dtype)  # the stored size
+        assert torch.equal(o_st, got_s.cpu())
+        if dtype == torch.float32:
+            np.testing.assert_allclose(log.cpu().numpy().astype(np.float64), np.log(o_s.astype(np.float64)),
+                                       rtol=2.5e-7, atol=1e-7)
+        else:
+            assert torch.equal(log.cpu(), torch.from_numpy(np.log(o_st.float().numpy())).to(dtype))
+    if dtype != torch.float32 and C % 8 == 0:
+        w = dev(1.0 + 0.1 * synth.normal_like((C,), seed + 3), dtype)
+        b = dev(0.1 * synth.normal_like((C,), seed + 4), dtype)
+        a = dev(0.5 * synth.normal_like((n, T, C), seed + 5), dtype)
+        base = _abi.merge_wavg_ln(merge.plan, x, size, w, b, 1e-6, addend=a)
+        got = _abi.merge_wavg_ln(merge.plan, x, size, w, b, 1e-6, addend=a, log_size=True)
+        for g_, w_ in zip(got, base):
+            assert torch.equal(g_, w_)
+        assert torch.equal(got[2]._tome_log, got[2].log())
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_log_size_regrouped_and_all_integer_sizes(dtype):
+    """(a) the regrouped entries emit the same log; (b) the kernel's logf equals torch's for every integer token
+    size a 16-frame clip can reach (1..1568) -- sizes are sums of ones in every model of the reference."""
+    from tome import _abi
+    tm = _tome()
+    B, F, P, C, r = 2, 8, 196, 768, 16
+    metric = dev(synth.normal_like((B * F, P, 64), 5))
+    x_full = dev(synth.normal_like((B, 1 + P * F, C), 6), dtype)
+    size = dev(synth.small_ints((B * F, P, 1), 7, 1, 9), dtype)
+    merge, _ = tm.bipartite_soft_matching(metric, r)
+    x0, s0 = _abi.merge_wavg_regrouped(merge.plan, x_full, size, F)
+    x1, s1 = _abi.merge_wavg_regrouped(merge.plan, x_full, size, F, log_size=True)
+    assert torch.equal(x0, x1) and torch.equal(s0, s1) and torch.equal(s1._tome_log, s1.log())
+    if dtype != torch.float32:
+        w = dev(1.0 + 0.1 * synth.normal_like((C,), 8), dtype)
+        b = dev(0.1 * synth.normal_like((C,), 9), dtype)
+        got = _abi.merge_wavg_regrouped(merge.plan, x_full, size, F, ln=(w, b, 1e-6), log_size=True)
+        assert torch.equal(got[0], x0) and torch.equal(got[2]._tome_log, s0.log())
+    # (b): one group whose token t has size t+1, nothing but the smallest r=1 merge
+    T = 1568
+    sizes = torch.arange(1, T + 1, dtype=torch.float32).reshape(1, T, 1)
+    m2 = dev(synth.normal_like((1, T, 8), 11))
+    mg, _ = tm.bipartite_soft_matching(m2, 1)
+    xs = dev(synth.normal_like((1, T, 8), 12))
+    _, s_out = tm.merge_wavg(mg, xs, sizes.to(DEV), log_size=True)
+    assert torch.equal(s_out._tome_log, s_out.log())
+    assert float(s_out.sum()) == float(sizes.sum())

@@ -359,7 +359,7 @@ static int launch_merge_rows(const void *x, const void *size, int64_t n, int64_t
                              const int64_t *src, const int64_t *dst, const int64_t *unm, int distill,
                              const uint8_t *keep, void *xout, void *sout, hipStream_t st,
                              const TokLayout *lin_p = nullptr, const TokLayout *lout_p = nullptr, int cls_rows = 0,
-                             const LnArgs *ln_p = nullptr) {
+                             const LnArgs *ln_p = nullptr, void *lsout = nullptr) {
     constexpr int VEC = 16 / sizeof(TX);
     const int64_t To = T - r;
     const TokLayout lin = lin_p ? *lin_p : contiguous_layout(T, C);
@@ -393,20 +393,20 @@ static int launch_merge_rows(const void *x, const void *size, int64_t n, int64_t
                 if (nit == 3)
                     hipLaunchKernelGGL((k_merge_rows_fast<TX, TS, OP, 3, true>), grid, dim3(256), 0, st, (const TX *)x,
                                        (const TS *)size, (int)n, (int)T, (int)C, (int)r, R, (int)cpr, src, dst, unm,
-                                       distill, keep, (TX *)xout, (TS *)sout, lin, lout, cls_rows, *ln_p);
+                                       distill, keep, (TX *)xout, (TS *)sout, lin, lout, cls_rows, *ln_p, (TS *)lsout);
                 else
                     hipLaunchKernelGGL((k_merge_rows_fast<TX, TS, OP, 6, true>), grid, dim3(256), 0, st, (const TX *)x,
                                        (const TS *)size, (int)n, (int)T, (int)C, (int)r, R, (int)cpr, src, dst, unm,
-                                       distill, keep, (TX *)xout, (TS *)sout, lin, lout, cls_rows, *ln_p);
+                                       distill, keep, (TX *)xout, (TS *)sout, lin, lout, cls_rows, *ln_p, (TS *)lsout);
             }
         } else if (nit == 3)
             hipLaunchKernelGGL((k_merge_rows_fast<TX, TS, OP, 3>), grid, dim3(256), 0, st, (const TX *)x,
                                (const TS *)size, (int)n, (int)T, (int)C, (int)r, R, (int)cpr, src, dst, unm, distill,
-                               keep, (TX *)xout, (TS *)sout, lin, lout, cls_rows, no_ln);
+                               keep, (TX *)xout, (TS *)sout, lin, lout, cls_rows, no_ln, (TS *)lsout);
         else
             hipLaunchKernelGGL((k_merge_rows_fast<TX, TS, OP, 6>), grid, dim3(256), 0, st, (const TX *)x,
                                (const TS *)size, (int)n, (int)T, (int)C, (int)r, R, (int)cpr, src, dst, unm, distill,
-                               keep, (TX *)xout, (TS *)sout, lin, lout, cls_rows, no_ln);
+                               keep, (TX *)xout, (TS *)sout, lin, lout, cls_rows, no_ln, (TS *)lsout);
         return check_launch("k_merge_rows_fast");
     }
     if (cls_rows || ln_p)
@@ -416,11 +416,11 @@ static int launch_merge_rows(const void *x, const void *size, int64_t n, int64_t
     if (vec_ok)
         hipLaunchKernelGGL((k_merge_rows<TX, TS, VEC, OP>), dim3(nb), dim3(256), 0, st, (const TX *)x,
                            (const TS *)size, (int)n, (int)T, (int)C, (int)r, src, dst, unm, distill, keep, (TX *)xout,
-                           (TS *)sout, lin, lout);
+                           (TS *)sout, lin, lout, (TS *)lsout);
     else
         hipLaunchKernelGGL((k_merge_rows<TX, TS, 1, OP>), dim3(nb), dim3(256), 0, st, (const TX *)x,
                            (const TS *)size, (int)n, (int)T, (int)C, (int)r, src, dst, unm, distill, keep, (TX *)xout,
-                           (TS *)sout, lin, lout);
+                           (TS *)sout, lin, lout, (TS *)lsout);
     return check_launch("k_merge_rows");
 }
 
@@ -435,14 +435,14 @@ static int check_merge_args(const char *who, const void *x, int64_t n, int64_t T
 extern "C" int tome_merge_wavg(const void *x, int x_dtype, const void *size, int size_dtype, int64_t n, int64_t T,
                                int64_t C, int64_t r, const int64_t *src_idx, const int64_t *dst_idx,
                                const int64_t *unm_idx, int distill_token, const uint8_t *edge_keep, void *x_out,
-                               void *size_out, tome_stream_t stream) {
+                               void *size_out, void *log_size_out, tome_stream_t stream) {
     if (int rc = check_merge_args("tome_merge_wavg", x, n, T, C, r, x_out)) return rc;
     if (!src_idx || !dst_idx || (!unm_idx && (T + 1) / 2 > r) || !size_out)
         return fail(TOME_EINVAL, "tome_merge_wavg: null buffer");
     hipStream_t st = (hipStream_t)stream;
 #define WAVG(TX, TS)                                                                                         \
     return launch_merge_rows<TX, TS, OP_WAVG>(x, size, n, T, C, r, src_idx, dst_idx, unm_idx, distill_token, \
-                                              edge_keep, x_out, size_out, st)
+                                              edge_keep, x_out, size_out, st, nullptr, nullptr, 0, nullptr, log_size_out)
     if (x_dtype == TOME_F32 && size_dtype == TOME_F32) WAVG(float, float);
     if (x_dtype == TOME_BF16 && size_dtype == TOME_BF16) WAVG(bf16_t, bf16_t);
     if (x_dtype == TOME_BF16 && size_dtype == TOME_F32) WAVG(bf16_t, float);
@@ -456,7 +456,8 @@ extern "C" int tome_merge_wavg_ln(const void *x, int x_dtype, const void *size, 
                                   int64_t C, int64_t r, const int64_t *src_idx, const int64_t *dst_idx,
                                   const int64_t *unm_idx, int distill_token, const uint8_t *edge_keep,
                                   const void *ln_weight, const void *ln_bias, float eps, const void *addend,
-                                  void *x_out, void *y_out, void *size_out, tome_stream_t stream) {
+                                  void *x_out, void *y_out, void *size_out, void *log_size_out,
+                                  tome_stream_t stream) {
     if (int rc = check_merge_args("tome_merge_wavg_ln", x, n, T, C, r, x_out)) return rc;
     if (addend && !aligned16(addend)) return fail(TOME_EINVAL, "tome_merge_wavg_ln: addend not 16-byte aligned");
     if (!src_idx || !dst_idx || (!unm_idx && (T + 1) / 2 > r) || !size_out || !y_out || !ln_weight || !ln_bias)
@@ -465,7 +466,7 @@ extern "C" int tome_merge_wavg_ln(const void *x, int x_dtype, const void *size, 
     hipStream_t st = (hipStream_t)stream;
 #define WAVGLN(TX, TS)                                                                                         \
     return launch_merge_rows<TX, TS, OP_WAVG>(x, size, n, T, C, r, src_idx, dst_idx, unm_idx, distill_token,   \
-                                              edge_keep, x_out, size_out, st, nullptr, nullptr, 0, &ln)
+                                              edge_keep, x_out, size_out, st, nullptr, nullptr, 0, &ln, log_size_out)
     if (x_dtype == TOME_BF16 && size_dtype == TOME_BF16) WAVGLN(bf16_t, bf16_t);
     if (x_dtype == TOME_BF16 && size_dtype == TOME_F32) WAVGLN(bf16_t, float);
     if (x_dtype == TOME_F16 && size_dtype == TOME_F16) WAVGLN(f16_t, f16_t);
@@ -477,8 +478,8 @@ extern "C" int tome_merge_wavg_ln(const void *x, int x_dtype, const void *size, 
 static int merge_wavg_regrouped_impl(const char *who, const void *x, int x_dtype, const void *size, int size_dtype,
                                      int64_t B, int64_t F, int64_t P, int64_t C, int64_t r, int has_cls,
                                      const int64_t *src_idx, const int64_t *dst_idx, const int64_t *unm_idx,
-                                     const uint8_t *edge_keep, void *x_out, void *size_out, const LnArgs *ln,
-                                     tome_stream_t stream) {
+                                     const uint8_t *edge_keep, void *x_out, void *size_out, void *log_size_out,
+                                     const LnArgs *ln, tome_stream_t stream) {
     if (B <= 0 || F <= 0) return fail(TOME_EINVAL, "%s: bad shape", who);
     const int64_t n = B * F;
     if (int rc = check_merge_args(who, x, n, P, C, r, x_out)) return rc;
@@ -489,7 +490,7 @@ static int merge_wavg_regrouped_impl(const char *who, const void *x, int x_dtype
     hipStream_t st = (hipStream_t)stream;
 #define WAVGR(TX, TS)                                                                                         \
     return launch_merge_rows<TX, TS, OP_WAVG>(x, size, n, P, C, r, src_idx, dst_idx, unm_idx, 0, edge_keep, x_out, \
-                                              size_out, st, &lin, &lout, cls ? (int)B : 0, ln)
+                                              size_out, st, &lin, &lout, cls ? (int)B : 0, ln, log_size_out)
     if (x_dtype == TOME_F32 && size_dtype == TOME_F32) WAVGR(float, float);
     if (x_dtype == TOME_BF16 && size_dtype == TOME_BF16) WAVGR(bf16_t, bf16_t);
     if (x_dtype == TOME_BF16 && size_dtype == TOME_F32) WAVGR(bf16_t, float);
@@ -503,9 +504,9 @@ extern "C" int tome_merge_wavg_regrouped(const void *x, int x_dtype, const void 
                                          int64_t F, int64_t P, int64_t C, int64_t r, int has_cls,
                                          const int64_t *src_idx, const int64_t *dst_idx, const int64_t *unm_idx,
                                          const uint8_t *edge_keep, void *x_out, void *size_out,
-                                         tome_stream_t stream) {
+                                         void *log_size_out, tome_stream_t stream) {
     return merge_wavg_regrouped_impl("tome_merge_wavg_regrouped", x, x_dtype, size, size_dtype, B, F, P, C, r, has_cls,
-                                     src_idx, dst_idx, unm_idx, edge_keep, x_out, size_out, nullptr, stream);
+                                     src_idx, dst_idx, unm_idx, edge_keep, x_out, size_out, log_size_out, nullptr, stream);
 }
 
 extern "C" int tome_merge_wavg_regrouped_ln(const void *x, int x_dtype, const void *size, int size_dtype, int64_t B,
@@ -513,13 +514,14 @@ extern "C" int tome_merge_wavg_regrouped_ln(const void *x, int x_dtype, const vo
                                             const int64_t *src_idx, const int64_t *dst_idx,
                                             const int64_t *unm_idx, const uint8_t *edge_keep, const void *ln_weight,
                                             const void *ln_bias, float eps, const void *addend, void *x_out,
-                                            void *y_out, void *size_out, tome_stream_t stream) {
+                                            void *y_out, void *size_out, void *log_size_out,
+                                            tome_stream_t stream) {
     if (!y_out || !ln_weight || !ln_bias) return fail(TOME_EINVAL, "tome_merge_wavg_regrouped_ln: null buffer");
     if (x_dtype == TOME_F32) return fail(TOME_EINVAL, "tome_merge_wavg_regrouped_ln: 16-bit tokens only");
     if (addend && !aligned16(addend)) return fail(TOME_EINVAL, "tome_merge_wavg_regrouped_ln: addend alignment");
     const LnArgs ln{ln_weight, ln_bias, y_out, eps, addend};
     return merge_wavg_regrouped_impl("tome_merge_wavg_regrouped_ln", x, x_dtype, size, size_dtype, B, F, P, C, r,
-                                     has_cls, src_idx, dst_idx, unm_idx, edge_keep, x_out, size_out, &ln, stream);
+                                     has_cls, src_idx, dst_idx, unm_idx, edge_keep, x_out, size_out, log_size_out, &ln, stream);
 }
 
 extern "C" int tome_add_layernorm(const void *x, const void *addend, int dtype, int64_t rows, int64_t C,

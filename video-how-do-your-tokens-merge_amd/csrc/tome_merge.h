@@ -47,6 +47,16 @@ __device__ __forceinline__ Pack<TX, VEC> add_packs(const Pack<TX, VEC> &x, const
     return o;
 }
 
+// size' of one output row, and -- for the proportional-attention bias of the next block
+// (`size.log()`, tome/patch/videomae.py:62-63, timesformer.py:73-74, motionformer.py:107-111, vivit.py:103-104)
+// -- log of the STORED size, fp32 logf rounded to the size dtype: what torch's `size.log()` gives on this device.
+template <typename TS>
+__device__ __forceinline__ void store_size(TS *__restrict__ srow, TS *__restrict__ lrow, float s) {
+    const TS st = from_f32<TS>(s);
+    *srow = st;
+    if (lrow) *lrow = from_f32<TS>(logf(to_f32(st)));
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
@@ -68,7 +78,7 @@ __device__ __forceinline__ void merge_dst_row(const TX *__restrict__ xg, const T
                                               const int64_t *__restrict__ dstg, const uint8_t *__restrict__ keep,
                                               TX *__restrict__ orow, TS *__restrict__ srow, int lane,
                                               const LnArgs *ln = nullptr, TX *__restrict__ yrow = nullptr,
-                                              const TX *__restrict__ ag = nullptr) {
+                                              const TX *__restrict__ ag = nullptr, TS *__restrict__ lrow = nullptr) {
     const int t = 2 * j + 1;
     const TX *xr = xg + (int64_t)t * tstride;
     float s_own = 1.0f;
@@ -201,7 +211,7 @@ __device__ __forceinline__ void merge_dst_row(const TX *__restrict__ xg, const T
         }
         if (a0) store_pack<TX, VEC>(orow + c0, acc0);
         if (a1) store_pack<TX, VEC>(orow + c1, acc1);
-        if (OP == OP_WAVG && lane == 0) *srow = from_f32<TS>(ssum);
+        if (OP == OP_WAVG && lane == 0) store_size<TS>(srow, lrow, ssum);
         if (LN) {
             // LayerNorm of the row as stored (rounded to the token dtype), the whole row is in this wave
             float part = 0.0f;
@@ -318,7 +328,7 @@ __device__ __forceinline__ void merge_dst_row(const TX *__restrict__ xg, const T
             store_pack<TX, VEC>(orow + c, acc);
         }
     }
-    if (OP == OP_WAVG && lane == 0) *srow = from_f32<TS>(ssum);
+    if (OP == OP_WAVG && lane == 0) store_size<TS>(srow, lrow, ssum);
 }
 
 // inverse of the output layout (merge.py:82-85): output row o -> (is it a B/dst row?, index in its set)
@@ -341,7 +351,8 @@ __global__ __launch_bounds__(256) void k_merge_rows(const TX *__restrict__ x, co
                                                     const int64_t *__restrict__ dst_idx,
                                                     const int64_t *__restrict__ unm_idx, int distill,
                                                     const uint8_t *__restrict__ keep, TX *__restrict__ xout,
-                                                    TS *__restrict__ sout, TokLayout lin, TokLayout lout) {
+                                                    TS *__restrict__ sout, TokLayout lin, TokLayout lout,
+                                                    TS *__restrict__ lsout) {
     const int lane = threadIdx.x & 63;
     const int To = T_ - r;
     const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -370,12 +381,13 @@ __global__ __launch_bounds__(256) void k_merge_rows(const TX *__restrict__ x, co
             }
             store_pack<TX, VEC>(orow + c, v);
         }
-        if (OP == OP_WAVG && lane == 0) sout[row] = from_f32<TS>(s);
+        if (OP == OP_WAVG && lane == 0) store_size<TS>(sout + row, lsout ? lsout + row : nullptr, s);
         return;
     }
     merge_dst_row<TX, TS, VEC, OP>(xg, sg, C, lin.tok_stride, r, g, idx, src_idx ? src_idx + (int64_t)g * r : nullptr,
                                    dst_idx ? dst_idx + (int64_t)g * r : nullptr, keep, orow,
-                                   sout ? sout + row : nullptr, lane);
+                                   sout ? sout + row : nullptr, lane, nullptr, nullptr, nullptr,
+                                   lsout ? lsout + row : nullptr);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -397,7 +409,7 @@ __global__ __launch_bounds__(256) void k_merge_rows_fast(const TX *__restrict__ 
                                                          const int64_t *__restrict__ unm_idx, int distill,
                                                          const uint8_t *__restrict__ keep, TX *__restrict__ xout,
                                                          TS *__restrict__ sout, TokLayout lin, TokLayout lout,
-                                                         int cls_rows, LnArgs ln) {
+                                                         int cls_rows, LnArgs ln, TS *__restrict__ lsout) {
     constexpr int VEC = 16 / sizeof(TX);
     const int lane = threadIdx.x & 63;
     const int To = T_ - r;
@@ -492,7 +504,8 @@ __global__ __launch_bounds__(256) void k_merge_rows_fast(const TX *__restrict__ 
             src_idx + (int64_t)g * r, dstg, keep, group_ptr(xout, lout, g) + (int64_t)o * lout.tok_stride,
             sout ? sout + (int64_t)g * To + o : nullptr, lane, &ln,
             LN ? group_ptr(reinterpret_cast<TX *>(ln.y), lout, g) + (int64_t)o * lout.tok_stride : nullptr,
-            (LN && ln.addend) ? group_ptr(reinterpret_cast<const TX *>(ln.addend), lin, g) : nullptr);
+            (LN && ln.addend) ? group_ptr(reinterpret_cast<const TX *>(ln.addend), lin, g) : nullptr,
+            lsout ? lsout + (int64_t)g * To + o : nullptr);
         return;
     }
     const int g = (int)(w / rg_per_group);
@@ -674,7 +687,8 @@ __global__ __launch_bounds__(256) void k_merge_rows_fast(const TX *__restrict__ 
     }
     if (OP == OP_WAVG && lane < R && my_valid) {
         const bool mine_has_edges = lane == 0 ? e0 : (lane == 1 ? e1 : (lane == 2 ? e2 : e3));
-        if (!mine_has_edges) sout[(int64_t)g * To + o0 + lane] = from_f32<TS>(my_s);
+        if (!mine_has_edges)
+            store_size<TS>(sout + (int64_t)g * To + o0 + lane, lsout ? lsout + (int64_t)g * To + o0 + lane : nullptr, my_s);
     }
 }
 

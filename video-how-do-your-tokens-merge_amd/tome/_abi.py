@@ -23,7 +23,7 @@ SYMBOLS = (
     "tome_profile_enable", "tome_profile_read",
 )
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 DTYPES = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}
 MODES = {"sum": 0, "mean": 1, "amax": 2, "max": 2, "prod": 3, "amin": 4, "min": 4}
 
@@ -64,15 +64,16 @@ def lib() -> ctypes.CDLL:
     L.tome_edge_keep.restype = i32
     L.tome_edge_keep.argtypes = [vp, vp, i64, i64, i64, ctypes.c_float, vp, vp]
     L.tome_merge_wavg.restype = i32
-    L.tome_merge_wavg.argtypes = [vp, i32, vp, i32, i64, i64, i64, i64, vp, vp, vp, i32, vp, vp, vp, vp]
+    L.tome_merge_wavg.argtypes = [vp, i32, vp, i32, i64, i64, i64, i64, vp, vp, vp, i32, vp, vp, vp, vp, vp]
     L.tome_merge_wavg_ln.restype = i32
     L.tome_merge_wavg_ln.argtypes = [vp, i32, vp, i32, i64, i64, i64, i64, vp, vp, vp, i32, vp, vp, vp, ctypes.c_float,
-                                     vp, vp, vp, vp, vp]
+                                     vp, vp, vp, vp, vp, vp]
     L.tome_merge_wavg_regrouped.restype = i32
-    L.tome_merge_wavg_regrouped.argtypes = [vp, i32, vp, i32, i64, i64, i64, i64, i64, i32, vp, vp, vp, vp, vp, vp, vp]
+    L.tome_merge_wavg_regrouped.argtypes = [vp, i32, vp, i32, i64, i64, i64, i64, i64, i32, vp, vp, vp, vp, vp, vp, vp,
+                                            vp]
     L.tome_merge_wavg_regrouped_ln.restype = i32
     L.tome_merge_wavg_regrouped_ln.argtypes = [vp, i32, vp, i32, i64, i64, i64, i64, i64, i32, vp, vp, vp, vp, vp, vp,
-                                               ctypes.c_float, vp, vp, vp, vp, vp]
+                                               ctypes.c_float, vp, vp, vp, vp, vp, vp]
     L.tome_add_layernorm.restype = i32
     L.tome_add_layernorm.argtypes = [vp, vp, i32, i64, i64, vp, vp, ctypes.c_float, vp, vp, vp]
     L.tome_merge.restype = i32
@@ -290,7 +291,24 @@ def _prep_x(plan: MatchPlan, x: torch.Tensor, what: str, tokens: int) -> torch.T
     return x if x.is_contiguous() else x.contiguous()
 
 
-def merge_wavg(plan: MatchPlan, x: torch.Tensor, size: Optional[torch.Tensor]):
+def _log_size_like(s_out: torch.Tensor, want: bool) -> Optional[torch.Tensor]:
+    """Buffer for log(size') -- the proportional-attention bias of the next block (`size.log()`,
+    tome/patch/videomae.py:62-63).  It travels as the attribute `_tome_log` of the size tensor it belongs to, so
+    a consumer that finds it (`log_of_size`) can never pair it with another size."""
+    if not want:
+        return None
+    log = torch.empty_like(s_out)
+    s_out._tome_log = log
+    return log
+
+
+def log_of_size(size: torch.Tensor) -> torch.Tensor:
+    """`size.log()`; free when the merge kernel that produced `size` already emitted it."""
+    log = getattr(size, "_tome_log", None)
+    return log if log is not None else size.log()
+
+
+def merge_wavg(plan: MatchPlan, x: torch.Tensor, size: Optional[torch.Tensor], log_size: bool = False):
     x = _prep_x(plan, x, "merge_wavg(x)", plan.T)
     n, T, C = x.shape
     xcode = dtype_code(x, "x")
@@ -307,10 +325,12 @@ def merge_wavg(plan: MatchPlan, x: torch.Tensor, size: Optional[torch.Tensor]):
     scode = DTYPES[sdtype]
     x_out = torch.empty((n, T - plan.r, C), dtype=x.dtype, device=x.device)
     s_out = torch.empty((n, T - plan.r, 1), dtype=sdtype, device=x.device)
+    log = _log_size_like(s_out, log_size)
     with _on_device(x.device):
         rc = lib().tome_merge_wavg(x.data_ptr(), xcode, _ptr(size), scode, n, T, C, plan.r, plan.src_idx.data_ptr(),
                                    plan.dst_idx.data_ptr(), plan.unm_idx.data_ptr(), int(plan.distill_token),
-                                   _ptr(plan.edge_keep), x_out.data_ptr(), s_out.data_ptr(), _stream(x.device))
+                                   _ptr(plan.edge_keep), x_out.data_ptr(), s_out.data_ptr(), _ptr(log),
+                                   _stream(x.device))
     _check(rc, "tome_merge_wavg")
     return x_out, s_out
 
@@ -325,7 +345,7 @@ def ln_fusable(x: torch.Tensor, norm) -> bool:
 
 
 def merge_wavg_ln(plan: MatchPlan, x: torch.Tensor, size: Optional[torch.Tensor], weight: torch.Tensor,
-                  bias: torch.Tensor, eps: float, addend: Optional[torch.Tensor] = None):
+                  bias: torch.Tensor, eps: float, addend: Optional[torch.Tensor] = None, log_size: bool = False):
     """merge_wavg + LayerNorm of the merged tokens in one launch: returns (x_out, y_out, size_out).  With
     `addend` the merged tokens are `x + addend` (the residual in front of the merge, added while loading)."""
     x = _prep_x(plan, x, "merge_wavg_ln(x)", plan.T)
@@ -347,12 +367,13 @@ def merge_wavg_ln(plan: MatchPlan, x: torch.Tensor, size: Optional[torch.Tensor]
     x_out = torch.empty((n, T - plan.r, C), dtype=x.dtype, device=x.device)
     y_out = torch.empty_like(x_out)
     s_out = torch.empty((n, T - plan.r, 1), dtype=sdtype, device=x.device)
+    log = _log_size_like(s_out, log_size)
     with _on_device(x.device):
         rc = lib().tome_merge_wavg_ln(x.data_ptr(), xcode, _ptr(size), DTYPES[sdtype], n, T, C, plan.r,
                                       plan.src_idx.data_ptr(), plan.dst_idx.data_ptr(), plan.unm_idx.data_ptr(),
                                       int(plan.distill_token), _ptr(plan.edge_keep), weight.data_ptr(), bias.data_ptr(),
                                       float(eps), _ptr(addend), x_out.data_ptr(), y_out.data_ptr(), s_out.data_ptr(),
-                                      _stream(x.device))
+                                      _ptr(log), _stream(x.device))
     _check(rc, "tome_merge_wavg_ln")
     return x_out, y_out, s_out
 
@@ -376,7 +397,8 @@ def add_layernorm(x: torch.Tensor, addend: torch.Tensor, weight: torch.Tensor, b
 
 
 def merge_wavg_regrouped(plan: MatchPlan, x_full: torch.Tensor, size: Optional[torch.Tensor], frames: int,
-                         has_cls: bool = True, ln=None, addend: Optional[torch.Tensor] = None):
+                         has_cls: bool = True, ln=None, addend: Optional[torch.Tensor] = None,
+                         log_size: bool = False):
     """merge_wavg on the interleaved layout of TimeSformer / Motionformer: x_full [B, has_cls + P*F, C] whose
     token has_cls + p*F + f belongs to group b*F + f; returns x_out [B, has_cls + (P-r)*F, C] and size
     [B*F, P-r, 1].  Replaces rearrange -> merge_wavg -> rearrange -> cat (timesformer.py:89-107).
@@ -408,6 +430,7 @@ def merge_wavg_regrouped(plan: MatchPlan, x_full: torch.Tensor, size: Optional[t
         sdtype = x_full.dtype
     x_out = torch.empty((B, cls + (P - plan.r) * F, C), dtype=x_full.dtype, device=x_full.device)
     s_out = torch.empty((plan.n, P - plan.r, 1), dtype=sdtype, device=x_full.device)
+    log = _log_size_like(s_out, log_size)
     if ln is None:
         if addend is not None:
             raise TomeHipError("merge_wavg_regrouped: addend is only fused together with ln")
@@ -415,7 +438,7 @@ def merge_wavg_regrouped(plan: MatchPlan, x_full: torch.Tensor, size: Optional[t
             rc = lib().tome_merge_wavg_regrouped(x_full.data_ptr(), xcode, _ptr(size), DTYPES[sdtype], B, F, P, C,
                                                  plan.r, cls, plan.src_idx.data_ptr(), plan.dst_idx.data_ptr(),
                                                  plan.unm_idx.data_ptr(), _ptr(plan.edge_keep), x_out.data_ptr(),
-                                                 s_out.data_ptr(), _stream(x_full.device))
+                                                 s_out.data_ptr(), _ptr(log), _stream(x_full.device))
         _check(rc, "tome_merge_wavg_regrouped")
         return x_out, s_out
     weight, bias, eps = ln
@@ -429,7 +452,8 @@ def merge_wavg_regrouped(plan: MatchPlan, x_full: torch.Tensor, size: Optional[t
                                                 plan.r, cls, plan.src_idx.data_ptr(), plan.dst_idx.data_ptr(),
                                                 plan.unm_idx.data_ptr(), _ptr(plan.edge_keep), weight.data_ptr(),
                                                 bias.data_ptr(), float(eps), _ptr(addend), x_out.data_ptr(),
-                                                y_out.data_ptr(), s_out.data_ptr(), _stream(x_full.device))
+                                                y_out.data_ptr(), s_out.data_ptr(), _ptr(log),
+                                                _stream(x_full.device))
     _check(rc, "tome_merge_wavg_regrouped_ln")
     return x_out, y_out, s_out
 

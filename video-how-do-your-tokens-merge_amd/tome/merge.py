@@ -231,13 +231,15 @@ def random_bipartite_soft_matching(metric: torch.Tensor, r: int) -> Tuple[Callab
     return merge, unmerge
 
 
-def merge_wavg(merge: Callable, x: torch.Tensor, size: Optional[torch.Tensor] = None
+def merge_wavg(merge: Callable, x: torch.Tensor, size: Optional[torch.Tensor] = None, log_size: bool = False
                ) -> Tuple[torch.Tensor, torch.Tensor]:
     """Size-weighted average merge; returns the merged tensor and the new token sizes.  With a merge
-    made by this package the whole ``x*size -> sum, sum -> x/size`` chain is one kernel launch."""
+    made by this package the whole ``x*size -> sum, sum -> x/size`` chain is one kernel launch.
+    ``log_size=True`` (not in the reference's signature) makes that launch also emit ``log(size')`` for the
+    next block's proportional-attention bias; consumers fetch it with ``_abi.log_of_size(size)``."""
     plan = getattr(merge, "plan", None)
     if plan is not None:
-        return _abi.merge_wavg(plan, x, size)
+        return _abi.merge_wavg(plan, x, size, log_size=log_size)
     # foreign callables (and do_nothing): the reference's op sequence on the tensors' own device
     if size is None:
         size = torch.ones_like(x[..., 0, None])

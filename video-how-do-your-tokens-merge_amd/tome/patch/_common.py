@@ -90,7 +90,7 @@ def reduce_merge(metric, x, info, r):
     if info["trace_source"]:
         info["source"] = merge_source(merge, x, info["source"])
     before = x.size(1)
-    x, info["size"] = merge_wavg(merge, x, info["size"])
+    x, info["size"] = merge_wavg(merge, x, info["size"], log_size=info["prop_attn"])
     if info["verbose"]:
         print(f"Merged {before} to {x.size(1)} tokens")
     return x
@@ -155,7 +155,7 @@ def merge_then_norm(metric, x, info, norm, reduction_function, plain_merge_fn, r
             info["source"] = merge_source(merge, x, info["source"])
         before = x.size(1)
         x, y, info["size"] = _abi.merge_wavg_ln(merge.plan, x, info["size"], norm.weight, norm.bias, norm.eps,
-                                                addend=residual)
+                                                addend=residual, log_size=info["prop_attn"])
         if info["verbose"]:
             print(f"Merged {before} to {x.size(1)} tokens")
         return x, y
@@ -180,7 +180,8 @@ def reduce_merge_regrouped(metric, x_full, info, r, frames, hybrid=False):
     if info["trace_source"]:
         shape_only = x_full.new_empty((plan.n, plan.T, 0))
         info["source"] = merge_source(merge, shape_only, info["source"])
-    x_out, info["size"] = _abi.merge_wavg_regrouped(plan, x_full, info["size"], frames, has_cls=True)
+    x_out, info["size"] = _abi.merge_wavg_regrouped(plan, x_full, info["size"], frames, has_cls=True,
+                                                    log_size=info["prop_attn"])
     if info["verbose"]:
         print(f"Merged {plan.T} to {plan.T - plan.r} tokens")
     return x_out
@@ -209,7 +210,8 @@ def merge_then_norm_regrouped(metric, x_full, info, norm, unfused_reduce, is_pla
     assert merge is not do_nothing
     plan = merge.plan
     x_out, y_out, info["size"] = _abi.merge_wavg_regrouped(plan, x_full, info["size"], frames, has_cls=True,
-                                                          ln=(norm.weight, norm.bias, norm.eps), addend=residual)
+                                                          ln=(norm.weight, norm.bias, norm.eps), addend=residual,
+                                                          log_size=info["prop_attn"])
     if info["verbose"]:
         print(f"Merged {plan.T} to {plan.T - plan.r} tokens")
     return x_out, y_out
@@ -238,7 +240,7 @@ def reduce_hybrid(metric, x, info, r):
     if info["trace_source"]:
         info["source"] = merge_source(merge, x, info["source"])
     before = x.size(1)
-    x, info["size"] = merge_wavg(merge, x, info["size"])
+    x, info["size"] = merge_wavg(merge, x, info["size"], log_size=info["prop_attn"])
     if info["verbose"]:
         print(f"Merged {before} to {x.size(1)} tokens")
     return x

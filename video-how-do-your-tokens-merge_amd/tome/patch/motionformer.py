@@ -8,6 +8,7 @@ import torch
 from einops import rearrange
 
 from . import _common as C
+from .. import _abi
 
 
 def _block_forward(self, x, seq_len=196, num_frames=8, approx="none", num_landmarks=128):
@@ -46,8 +47,8 @@ def _trajectory_forward(self, x, seq_len=196, num_frames=8, approx="none", num_l
     q_dot_k = rearrange(q_ @ k_.transpose(-2, -1), "b q (f n) -> b q f n", f=F) * self.scale
     if size is not None:
         q_dot_k = rearrange(q_dot_k, "(b h) q f n -> b h q (f n)", h=h, f=F)
-        size_seq = rearrange(size, "(b f) s i -> b (s f) i", f=F)
-        q_dot_k = q_dot_k + size_seq.log()[:, None, None, :, 0].to(q_dot_k.dtype)
+        log_seq = rearrange(_abi.log_of_size(size), "(b f) s i -> b (s f) i", f=F)  # log commutes with the regroup
+        q_dot_k = q_dot_k + log_seq[:, None, None, :, 0].to(q_dot_k.dtype)
         q_dot_k = rearrange(q_dot_k, "b h q (f n) -> (b h) q f n", h=h, f=F)
     attn = self.attn_drop(q_dot_k.softmax(dim=-1))
     v_ = rearrange(v_, "b (f n) d -> b f n d", f=F, n=P)

@@ -7,6 +7,7 @@ import torch
 import torch.nn.functional as F
 
 from . import _common as C
+from .. import _abi
 from ..merge import HeadMeanKeys
 
 
@@ -51,7 +52,7 @@ def _attention_forward(self, x, size: torch.Tensor = None):
     bias = None
     if size is not None:
         bias = torch.zeros(B, 1, N, N, dtype=q.dtype, device=q.device)
-        bias[:, :, 1:, 1:] = size.log()[:, None, None, :, 0].to(q.dtype)
+        bias[:, :, 1:, 1:] = _abi.log_of_size(size)[:, None, None, :, 0].to(q.dtype)
     drop_p = self.attn_drop.p if self.training else 0.0
     out = F.scaled_dot_product_attention(q, k, v, attn_mask=bias, dropout_p=drop_p, scale=self.scale)
     out = out.transpose(1, 2).reshape(B, N, Cc)

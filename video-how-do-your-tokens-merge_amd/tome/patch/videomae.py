@@ -12,6 +12,7 @@ import torch
 import torch.nn.functional as F
 
 from . import _common as C
+from .. import _abi
 from ..merge import HeadMeanKeys
 
 
@@ -50,7 +51,7 @@ def _attention_forward(self, x, size: torch.Tensor = None, head_aggregation: str
     qkv = F.linear(x, self.qkv.weight, bias).reshape(B, N, 3, self.num_heads, -1).permute(2, 0, 3, 1, 4)
     q, k, v = qkv[0], qkv[1], qkv[2]
     # softmax(q*scale @ k^T + log(size)) @ v, by the framework's fused attention
-    attn_bias = None if size is None else size.log()[:, None, None, :, 0].to(q.dtype)
+    attn_bias = None if size is None else _abi.log_of_size(size)[:, None, None, :, 0].to(q.dtype)
     drop_p = self.attn_drop.p if self.training else 0.0
     out = F.scaled_dot_product_attention(q, k, v, attn_mask=attn_bias, dropout_p=drop_p, scale=self.scale)
     out = self.proj_drop(self.proj(out.transpose(1, 2).reshape(B, N, -1)))

@@ -10,6 +10,7 @@ import torch
 import torch.nn.functional as F
 
 from . import _common as C
+from .. import _abi
 from ..merge import HeadMeanKeys
 
 
@@ -59,7 +60,7 @@ def _self_attention_forward(self, hidden_states, size=None, head_aggregation="me
         return t.view(B, N, H, hd).permute(0, 2, 1, 3)
 
     q, k, v = heads(self.query(hidden_states)), heads(self.key(hidden_states)), heads(self.value(hidden_states))
-    bias = None if size is None else size.log()[:, None, None, :, 0].to(q.dtype)
+    bias = None if size is None else _abi.log_of_size(size)[:, None, None, :, 0].to(q.dtype)
     probs = None
     if output_attentions or head_mask is not None:
         scores = torch.matmul(q, k.transpose(-1, -2)) / math.sqrt(hd)
