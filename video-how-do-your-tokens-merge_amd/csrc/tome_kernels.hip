@@ -375,12 +375,14 @@ static int launch_merge_rows(const void *x, const void *size, int64_t n, int64_t
             int v = e ? atoi(e) : 0;
             return (v == 3 || v == 6) ? v : 6;
         }();
+        // with the LayerNorm fused: 6 chunks per lane for x alone; with the residual stream next to it 3 per lane
+        // (77 instead of 107 VGPRs, six instead of four waves per SIMD) measured 5 % faster (124 vs 131 us)
         static const int nit_ln = [] {
             const char *e = getenv("TOME_MERGE_LN_NIT");
             int v = e ? atoi(e) : 0;
-            return (v == 3 || v == 6) ? v : 6;
+            return (v == 3 || v == 6) ? v : 0;
         }();
-        const int nit = (cpr <= 3 * WAVE) ? (ln_p ? nit_ln : nit_pref) : FAST_NIT;
+        const int nit = (cpr <= 3 * WAVE) ? (ln_p ? (nit_ln ? nit_ln : (ln_p->addend ? 3 : 6)) : nit_pref) : FAST_NIT;
         int R = (int)((nit * WAVE) / cpr);
         if (R > FAST_MAXR) R = FAST_MAXR;
         const int64_t waves = n * ((To + R - 1) / R) + (OP == OP_DROP ? 0 : n * r) + cls_rows;
@@ -534,18 +536,27 @@ extern "C" int tome_add_layernorm(const void *x, const void *addend, int dtype, 
     if (C % 8 || cpr > 2 * WAVE || !aligned16(x) || !aligned16(addend) || !aligned16(x_out) || !aligned16(y_out) ||
         !aligned16(ln_weight) || !aligned16(ln_bias))
         return fail(TOME_EINVAL, "tome_add_layernorm: C %% 8 == 0, C <= 1024 and 16-byte aligned buffers required");
-    int R = (int)((FAST_NIT * WAVE) / cpr);
+    static const int nit_env = [] {
+        const char *e = getenv("TOME_ADD_LN_NIT");  // 3 chunks per lane: 100.6 us vs 105 us with 6 (batch 64)
+        int v = e ? atoi(e) : 0;
+        return (v == 3 || v == 6) ? v : 3;
+    }();
+    const int nit = (cpr <= 3 * WAVE) ? nit_env : FAST_NIT;
+    int R = (int)((nit * WAVE) / cpr);
     if (R > FAST_MAXR) R = FAST_MAXR;
     const int64_t waves = (rows + R - 1) / R;
     const LnArgs ln{ln_weight, ln_bias, y_out, eps, nullptr};
     const dim3 grid((unsigned)((waves + 3) / 4));
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == TOME_BF16)
-        hipLaunchKernelGGL((k_add_ln_rows<bf16_t, FAST_NIT>), grid, dim3(256), 0, st, (const bf16_t *)x,
-                           (const bf16_t *)addend, rows, (int)C, R, (int)cpr, ln, (bf16_t *)x_out);
-    else
-        hipLaunchKernelGGL((k_add_ln_rows<f16_t, FAST_NIT>), grid, dim3(256), 0, st, (const f16_t *)x,
-                           (const f16_t *)addend, rows, (int)C, R, (int)cpr, ln, (f16_t *)x_out);
+#define ADDLN(TX, N)                                                                                              \
+    hipLaunchKernelGGL((k_add_ln_rows<TX, N>), grid, dim3(256), 0, st, (const TX *)x, (const TX *)addend, rows, \
+                       (int)C, R, (int)cpr, ln, (TX *)x_out)
+    if (dtype == TOME_BF16) {
+        if (nit == 3) ADDLN(bf16_t, 3); else ADDLN(bf16_t, 6);
+    } else {
+        if (nit == 3) ADDLN(f16_t, 3); else ADDLN(f16_t, 6);
+    }
+#undef ADDLN
     return check_launch("k_add_ln_rows");
 }
 
