@@ -9,6 +9,8 @@ from collections import OrderedDict
 
 import torch
 import torch.nn as nn
+
+from ._patchify import patch_tokens, tubelet_tokens  # noqa: F401
 from einops import rearrange
 
 
@@ -107,7 +109,7 @@ class PatchEmbed3D(nn.Module):
                               stride=(z_block_size, patch_size, patch_size))
 
     def forward(self, x):
-        return self.proj(x).flatten(2).transpose(1, 2)
+        return tubelet_tokens(self.proj, x)
 
 
 class Motionformer(nn.Module):

@@ -7,6 +7,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from ._patchify import patch_tokens, tubelet_tokens  # noqa: F401
+
 
 class Mlp(nn.Module):
     def __init__(self, dim, hidden, drop=0.0):
@@ -84,9 +86,8 @@ class PatchEmbed(nn.Module):
 
     def forward(self, x):
         B, C, T, H, W = x.shape
-        x = self.proj(x.transpose(1, 2).reshape(B * T, C, H, W))
-        Wp = x.size(-1)
-        return x.flatten(2).transpose(1, 2), T, Wp
+        x = patch_tokens(self.proj, x.transpose(1, 2).reshape(B * T, C, H, W))
+        return x, T, W // self.proj.kernel_size[1]
 
 
 class VisionTransformer(nn.Module):

@@ -12,6 +12,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from ._patchify import patch_tokens, tubelet_tokens  # noqa: F401
+
 
 def sincos_table(n_position: int, d_hid: int) -> torch.Tensor:
     """Fixed positional table: even channels sin, odd channels cos of pos / 10000^(2*(j//2)/d), evaluated in
@@ -86,7 +88,7 @@ class PatchEmbed(nn.Module):
                               stride=(tubelet_size, patch_size, patch_size))
 
     def forward(self, x):
-        return self.proj(x).flatten(2).transpose(1, 2)
+        return tubelet_tokens(self.proj, x)
 
 
 class VisionTransformer(nn.Module):

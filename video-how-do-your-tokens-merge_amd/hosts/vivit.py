@@ -12,6 +12,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from ._patchify import patch_tokens, tubelet_tokens  # noqa: F401
+
 
 def gelu_fast(x):
     return 0.5 * x * (1.0 + torch.tanh(x * 0.7978845608 * (1.0 + 0.044715 * x * x)))
@@ -35,7 +37,7 @@ class VivitTubeletEmbeddings(nn.Module):
         self.projection = nn.Conv3d(cfg.num_channels, cfg.hidden_size, kernel_size=cfg.tubelet_size, stride=cfg.tubelet_size)
 
     def forward(self, pixel_values):  # [B, T, C, H, W]
-        return self.projection(pixel_values.permute(0, 2, 1, 3, 4)).flatten(2).transpose(1, 2)
+        return tubelet_tokens(self.projection, pixel_values.permute(0, 2, 1, 3, 4))
 
 
 class VivitEmbeddings(nn.Module):
