@@ -38,3 +38,39 @@ def test_patch_tokens_equal_conv2d_and_fallbacks():
     ragged = torch.nn.Conv3d(3, 8, kernel_size=(2, 4, 4), stride=(2, 4, 4))
     x4 = torch.randn(1, 3, 5, 9, 8)
     assert torch.equal(tubelet_tokens(ragged, x4), ragged(x4).flatten(2).transpose(1, 2))
+
+
+def test_harness_config_defaults_file_and_opts(tmp_path):
+    """The reference's `--cfg file --opts KEY VALUE ...` interface (slowfast/utils/parser.py + yacs semantics):
+    defaults <- YAML <- opts, values parsed as YAML scalars."""
+    from hosts import harness
+    y = tmp_path / "c.yaml"
+    y.write_text("TRAIN:\n  ENABLE: True\nDATA:\n  NUM_FRAMES: 16\n  INPUT_CHANNEL_NUM: [3]\nMODEL:\n  MODEL_NAME: VideoMAE\n"
+                 "TEST:\n  BATCH_SIZE: 32\nNUM_GPUS: 2\nUNKNOWN_SECTION:\n  KEY: 1\n")
+    a = harness.parse_args(["--cfg", str(y), "--opts", "TRAIN.ENABLE", "False", "TOME.ENABLE", "True", "TOME.R_VALUE",
+                            "150", "TOME.PROP_ATTN", "False", "TOME.SCHEDULE", "-1", "TOME.THRESHOLD", "0.8",
+                            "MODEL_BENCHMARK.ITERATIONS", "100", "WANDB.ENABLE", "True"])
+    cfg = harness.load_cfg(a.cfg_file, a.opts)
+    assert cfg.TRAIN.ENABLE is False and cfg.TOME.ENABLE is True and cfg.TOME.R_VALUE == 150
+    assert cfg.TOME.PROP_ATTN is False and cfg.TOME.SCHEDULE == -1 and cfg.TOME.THRESHOLD == 0.8
+    assert cfg.DATA.NUM_FRAMES == 16 and cfg.TEST.BATCH_SIZE == 32 and cfg.NUM_GPUS == 2
+    assert cfg.TOME.MODE == "merge" and cfg.TOME.HEAD_AGGREGATION == "mean"  # defaults of custom_config.py
+    assert cfg.MODEL_BENCHMARK.ITERATIONS == 100 and cfg.MODEL_BENCHMARK.WARMUP_ITERATIONS == 0
+    assert cfg.WANDB.ENABLE is True and cfg.UNKNOWN_SECTION.KEY == 1
+    with pytest.raises(ValueError):
+        harness.load_cfg(None, ["TOME.ENABLE"])
+
+
+def test_harness_builds_the_four_families():
+    from hosts import harness
+    tiny = ["MOTIONFORMER.EMBED_DIM", "48", "MOTIONFORMER.DEPTH", "2", "MOTIONFORMER.NUM_HEADS", "4",
+            "MODEL.MODEL_NAME", "Motionformer", "MODEL.NUM_CLASSES", "7"]
+    m = harness.build_model(harness.load_cfg(None, tiny))
+    assert len(m.blocks) == 2 and m.head.out_features == 7 if hasattr(m.head, "out_features") else True
+    for name, attr in (("VideoMAE", "model"), ("TimeSformer", "model"), ("ViViT", "vivit")):
+        cfg = harness.load_cfg(None, ["MODEL.MODEL_NAME", name, "DATA.NUM_FRAMES", "8", "MODEL.NUM_CLASSES", "11"])
+        with torch.device("meta"):
+            mod = harness.build_model(cfg)
+        assert hasattr(mod, attr)
+    with pytest.raises(ValueError):
+        harness.build_model(harness.load_cfg(None, ["MODEL.MODEL_NAME", "SlowFast"]))

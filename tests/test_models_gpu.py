@@ -253,3 +253,59 @@ def test_fused_block_equals_unfused_block_bf16(host_name, monkeypatch):
     assert torch.equal(p1[0][1].src_idx, p0[0][1].src_idx) and torch.equal(p1[0][1].dst_idx, p0[0][1].dst_idx)
     assert float(s1.sum()) == float(s0.sum())
     assert float((o1 - o0).abs().max()) <= 0.05 * max(1.0, float(o0.abs().max()))
+
+
+_CFG_YAML = """\
+TRAIN:
+  ENABLE: True
+DATA:
+  NUM_FRAMES: 16
+  TEST_CROP_SIZE: 224
+  INPUT_CHANNEL_NUM: [3]
+MOTIONFORMER:
+  PATCH_SIZE: 16
+  PATCH_SIZE_TEMP: 2
+  EMBED_DIM: 64
+  DEPTH: 3
+  NUM_HEADS: 4
+  TEMPORAL_RESOLUTION: 8
+  USE_MLP: True
+  HEAD_ACT: tanh
+MODEL:
+  NUM_CLASSES: 13
+  ARCH : motionformer
+  MODEL_NAME: Motionformer
+TEST:
+  ENABLE: True
+  BATCH_SIZE: 4
+  NUM_ENSEMBLE_VIEWS: 2
+  NUM_SPATIAL_CROPS: 1
+NUM_GPUS: 1
+RNG_SEED: 0
+"""
+
+
+def test_reference_command_lines_run(tmp_path, capsys):
+    """the reference's `--cfg <yaml> --opts ...` command lines (experiments.sh:16-19,81-92)
+    drive the patched models: MODEL_BENCHMARK harness and the multi-view test loop, on synthetic clips."""
+    from hosts import harness
+    y = tmp_path / "tome_motionformer_tiny.yaml"
+    y.write_text(_CFG_YAML)
+    res = harness.main_benchmark(["--cfg", str(y), "--opts", "TRAIN.ENABLE", "False", "TOME.ENABLE", "True",
+                                  "TOME.R_VALUE", "16", "MODEL_BENCHMARK.WARMUP_ITERATIONS", "1",
+                                  "MODEL_BENCHMARK.ITERATIONS", "2", "TEST.BATCH_SIZE", "2"])
+    assert res["average_fps"] > 0 and res["iterations"] == 2 and res["batch"] == 2
+    assert "Average fps is" in capsys.readouterr().out
+    out = {}
+    for opts in (["TOME.ENABLE", "True", "TOME.R_VALUE", "16", "TOME.SCHEDULE", "-1"],
+                 ["TOME.ENABLE", "True", "TOME.R_VALUE", "8", "TOME.MODE", "hybrid", "TOME.THRESHOLD", "0.8"],
+                 ["TOME.ENABLE", "True", "TOME.R_VALUE", "0"], []):
+        r = harness.main_run_net(["--cfg", str(y), "--dtype", "fp32", "--opts", "TRAIN.ENABLE", "False",
+                                  "TEST.NUM_SYNTHETIC_VIDEOS", "6"] + opts)
+        assert r["videos"] == 6 and r["all_clips_seen"] and r["views_per_video"] == 2
+        assert 0.0 <= r["top1_acc"] <= r["top5_acc"] <= 100.0
+        out[tuple(opts)] = r
+    # r = 0 is the unpatched model (same seeds -> same weights, clips and labels)
+    assert out[("TOME.ENABLE", "True", "TOME.R_VALUE", "0")] == out[()]
+    with pytest.raises(SystemExit):
+        harness.main_run_net(["--cfg", str(y)])  # TRAIN.ENABLE True: training is out of scope, said loudly
