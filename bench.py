@@ -309,7 +309,9 @@ def main():
             },
             "top1": int(counts[0].item()), "top5": int(counts[1].item()),
         }
-        if not args.no_roofline:
+        if args.r <= 0:
+            out["roofline"] = None  # r = 0: the unmerged model, no merge-path kernel runs
+        elif not args.no_roofline:
             with torch.no_grad():
                 stats = measure_kernels(B, t0_tokens, args.r, dev)
             out["roofline"] = roofline_of(stats)
