@@ -1,12 +1,15 @@
-"""Same export names as the reference's tome/patch/__init__.py:1-11."""
-from .vivit import apply_patch as vivit
-from .vivit import apply_duplicate_patch as duplicate_vivit
-from .timesformer import apply_patch as timesformer
-from .timesformer import apply_duplicate_patch as duplicate_timesformer
-from .motionformer import apply_patch as motionformer
-from .motionformer import apply_duplicate_patch as duplicate_motionformer
-from .videomae import apply_patch as videomae
-from .videomae import apply_duplicate_patch as duplicate_videomae
+"""The eight entry points a driver picks from (`tome.patch.<family>` installs the patch on a model,
+`tome.patch.duplicate_<family>` inserts attend-and-merge-only copies of a layer) -- the public names of the
+reference's tome/patch package, which tools/test_net.py:259-283 and slowfast/utils/model_benchmark.py:82-103 select by
+MODEL.MODEL_NAME."""
+from importlib import import_module
 
-__all__ = ["vivit", "duplicate_vivit", "timesformer", "duplicate_timesformer", "motionformer",
-           "duplicate_motionformer", "videomae", "duplicate_videomae"]
+FAMILIES = ("videomae", "timesformer", "motionformer", "vivit")
+__all__ = []
+for _family in FAMILIES:
+    _mod = import_module(f"{__name__}.{_family}")
+    _exports = {_family: _mod.apply_patch, f"duplicate_{_family}": _mod.apply_duplicate_patch}
+    # the family names are rebound from the submodules to the functions, as the reference's package does
+    globals().update(_exports)
+    __all__ += list(_exports)
+del _family, _mod, _exports
