@@ -163,6 +163,13 @@ int tome_merge_wavg_regrouped_ln(const void *x, int x_dtype, const void *size, i
                                  const void *addend, void *x_out, void *y_out, void *size_out,
                                  void *log_size_out, tome_stream_t stream);
 
+/* tome_drop (below) on the regrouped layout of tome_merge_wavg_regrouped: timesformer_drop / motionformer_drop
+ * (tome/patch/timesformer.py:111-131, motionformer.py:172-193) without the permuted copies.
+ * x [B, has_cls + P*F, C] -> x_out [B, has_cls + (P-r)*F, C]; und_idx [B*F, ceil(P/2)-r].
+ * C * sizeof(dtype) must be a multiple of 16. */
+int tome_drop_regrouped(const void *x, int dtype, int64_t B, int64_t F, int64_t P, int64_t C, int64_t r,
+                        int has_cls, const int64_t *und_idx, void *x_out, tome_stream_t stream);
+
 /*
  * tome_add_layernorm  <-  the second residual of the patched block and the LayerNorm that consumes it:
  *     x = x + self.drop_path(self.mlp(self.norm2(x)))      (tome/patch/videomae.py:29)

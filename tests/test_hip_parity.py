@@ -642,3 +642,25 @@ def test_log_size_regrouped_and_all_integer_sizes(dtype):
     _, s_out = tm.merge_wavg(mg, xs, sizes.to(DEV), log_size=True)
     assert torch.equal(s_out._tome_log, s_out.log())
     assert float(s_out.sum()) == float(sizes.sum())
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,F,P,C,r", [(2, 4, 36, 32, 6), (3, 8, 196, 768, 16), (1, 8, 49, 64, 24), (2, 2, 9, 8, 4)])
+def test_drop_regrouped_equals_rearranged(B, F, P, C, r, dtype):
+    """tome_drop_regrouped == rearrange -> drop -> rearrange -> cat (timesformer.py:111-131): bit-identical rows,
+    class token copied through, and equal to the CPU oracle's drop on the regrouped tokens."""
+    from tome import _abi
+    tm = _tome()
+    metric = dev(synth.normal_like((B * F, P, 16), 400 + P))
+    x_full = dev(synth.normal_like((B, 1 + P * F, C), 401 + P), dtype)
+    drop = tm.bipartite_soft_matching_drop(metric, r)
+    plan = drop.plan
+    got = _abi.drop_regrouped(plan, x_full, F)
+    cls, body = x_full[:, :1], x_full[:, 1:]
+    grouped = body.reshape(B, P, F, C).permute(0, 2, 1, 3).reshape(B * F, P, C).contiguous()
+    d = drop(grouped)
+    want = torch.cat((cls, d.reshape(B, F, P - plan.r, C).permute(0, 2, 1, 3).reshape(B, (P - plan.r) * F, C)), dim=1)
+    assert torch.equal(got, want)
+    o_plan = oracle.match(metric, r)
+    o = oracle.drop(o_plan, grouped)
+    assert np.array_equal(d.float().cpu().numpy(), o)

@@ -117,6 +117,55 @@ def test_videomae_schedule_and_modes():
     assert model._tome_info["size"].shape[1] == 1568 - sum([32, 29, 26, 23, 20, 17, 14, 11, 8, 5, 2, 0])
 
 
+@pytest.mark.parametrize("family", ["timesformer", "motionformer"])
+def test_regrouped_models_drop_and_hybrid_modes(family):
+    """TimeSformer / Motionformer in drop, random_drop and hybrid mode (kernel-addressed groups,
+    tome_drop_regrouped / tome_merge_wavg_regrouped with edge flags) == the same model run through the
+    reference's own sequence rearrange -> reduce -> rearrange -> cat built from this package's grouped calls."""
+    tome, H = _hosts()
+    from tome.patch import _common as C
+    torch.manual_seed(0)
+    if family == "timesformer":
+        model = H["timesformer"].TimeSformer(num_frames=4, img_size=96, patch_size=16, embed_dim=64, depth=3, num_heads=2,
+                                             num_classes=5).to(DEV).eval()
+        clip = [torch.rand(2, 3, 4, 96, 96, device=DEV)]
+        patch = tome.patch.timesformer
+    else:
+        model = H["motionformer"].Motionformer(img_size=96, patch_size=16, patch_size_temp=2, temporal_resolution=4,
+                                               embed_dim=64, depth=3, num_heads=2, num_classes=5).to(DEV).eval()
+        clip = [torch.rand(2, 3, 8, 96, 96, device=DEV)]
+        patch = tome.patch.motionformer
+    for mode in ("drop", "hybrid"):
+        patch(model, mode=mode, threshold=0.9, prop_attn=True)
+        model.r = (6, 0)
+        with torch.no_grad():
+            got = model(clip)
+        sizes = model._tome_info["size"].clone()
+        # the same forward with the regrouped entry points replaced by explicit regrouping around the grouped ones
+        real_drop, real_merge = C.reduce_drop_regrouped, C.reduce_merge_regrouped
+
+        def via_views(reduce_grouped):
+            def f(metric, x_full, info, r, frames, **kw):
+                B, N, Cc = x_full.shape
+                P = (N - 1) // frames
+                body = x_full[:, 1:].reshape(B, P, frames, Cc).permute(0, 2, 1, 3).reshape(B * frames, P, Cc)
+                y = reduce_grouped(metric, body.contiguous(), info, r)
+                P2 = y.shape[1]
+                y = y.reshape(B, frames, P2, Cc).permute(0, 2, 1, 3).reshape(B, P2 * frames, Cc)
+                return torch.cat((x_full[:, :1], y), dim=1)
+            return f
+        C.reduce_drop_regrouped = via_views(C.reduce_drop)
+        C.reduce_merge_regrouped = via_views(C.reduce_hybrid)
+        try:
+            model.r = (6, 0)
+            with torch.no_grad():
+                want = model(clip)
+        finally:
+            C.reduce_drop_regrouped, C.reduce_merge_regrouped = real_drop, real_merge
+        assert torch.equal(model._tome_info["size"], sizes)
+        torch.testing.assert_close(got, want, rtol=0, atol=0)
+
+
 def test_vivit_structural():
     """ViViT: class token protected and first, token counts 3137 -> 3137 - 64*layers at reduced depth/width."""
     tome, H = _hosts()

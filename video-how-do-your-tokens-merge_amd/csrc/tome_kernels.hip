@@ -605,6 +605,27 @@ extern "C" int tome_drop(const void *x, int dtype, int64_t n, int64_t T, int64_t
                                 nullptr, out, (hipStream_t)stream);
 }
 
+// tome_drop on the interleaved layout of TimeSformer / Motionformer (class token kept aside and copied through)
+extern "C" int tome_drop_regrouped(const void *x, int dtype, int64_t B, int64_t F, int64_t P, int64_t C, int64_t r,
+                                   int has_cls, const int64_t *und_idx, void *x_out, tome_stream_t stream) {
+    if (B <= 0 || F <= 0) return fail(TOME_EINVAL, "tome_drop_regrouped: bad shape");
+    const int64_t n = B * F;
+    if (int rc = check_merge_args("tome_drop_regrouped", x, n, P, C, r, x_out)) return rc;
+    if (!und_idx && (P + 1) / 2 > r) return fail(TOME_EINVAL, "tome_drop_regrouped: null index buffer");
+    const int cls = has_cls ? 1 : 0;
+    const TokLayout lin{cls * C, (cls + P * F) * C, C, F * C, (int)F};
+    const TokLayout lout{cls * C, (cls + (P - r) * F) * C, C, F * C, (int)F};
+    hipStream_t st = (hipStream_t)stream;
+#define DROPR(TX)                                                                                              \
+    return launch_merge_rows<TX, float, OP_DROP>(x, nullptr, n, P, C, r, nullptr, nullptr, und_idx, 0, nullptr, \
+                                                 x_out, nullptr, st, &lin, &lout, cls ? (int)B : 0)
+    if (dtype == TOME_F32) DROPR(float);
+    if (dtype == TOME_BF16) DROPR(bf16_t);
+    if (dtype == TOME_F16) DROPR(f16_t);
+#undef DROPR
+    return fail(TOME_EINVAL, "tome_drop_regrouped: dtype %d", dtype);
+}
+
 template <typename TX>
 static int launch_unmerge(const void *x, int64_t n, int64_t T, int64_t C, int64_t r, const int64_t *src,
                           const int64_t *dst, const int64_t *unm, void *out, hipStream_t st) {

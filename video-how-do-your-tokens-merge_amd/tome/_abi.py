@@ -18,7 +18,7 @@ SYMBOLS = (
     "tome_abi_version", "tome_last_error", "tome_effective_r", "tome_match_workspace_bytes", "tome_match",
     "tome_match_keys",
     "tome_match_scores", "tome_edge_keep", "tome_merge_wavg", "tome_merge_wavg_ln", "tome_merge_wavg_regrouped",
-    "tome_merge_wavg_regrouped_ln", "tome_add_layernorm", "tome_merge", "tome_drop",
+    "tome_merge_wavg_regrouped_ln", "tome_add_layernorm", "tome_merge", "tome_drop", "tome_drop_regrouped",
     "tome_unmerge",
     "tome_profile_enable", "tome_profile_read",
 )
@@ -78,6 +78,8 @@ def lib() -> ctypes.CDLL:
     L.tome_add_layernorm.argtypes = [vp, vp, i32, i64, i64, vp, vp, ctypes.c_float, vp, vp, vp]
     L.tome_merge.restype = i32
     L.tome_merge.argtypes = [vp, i32, i64, i64, i64, i64, vp, vp, vp, i32, i32, vp, vp, vp]
+    L.tome_drop_regrouped.restype = i32
+    L.tome_drop_regrouped.argtypes = [vp, i32, i64, i64, i64, i64, i64, i32, vp, vp, vp]
     L.tome_drop.restype = i32
     L.tome_drop.argtypes = [vp, i32, i64, i64, i64, i64, vp, i32, vp, vp]
     L.tome_unmerge.restype = i32
@@ -480,6 +482,31 @@ def drop(plan: MatchPlan, x: torch.Tensor) -> torch.Tensor:
         rc = lib().tome_drop(x.data_ptr(), dtype_code(x, "x"), n, T, C, plan.r, plan.unm_idx.data_ptr(),
                              int(plan.distill_token), out.data_ptr(), _stream(x.device))
     _check(rc, "tome_drop")
+    return out
+
+
+def drop_regrouped(plan: MatchPlan, x_full: torch.Tensor, frames: int, has_cls: bool = True) -> torch.Tensor:
+    """drop on the interleaved layout (see merge_wavg_regrouped): x_full [B, has_cls + P*F, C] ->
+    [B, has_cls + (P-r)*F, C], replacing rearrange -> drop -> rearrange -> cat (timesformer.py:111-131)."""
+    require_device(x_full, "drop_regrouped(x)")
+    if x_full.dim() != 3:
+        raise TomeHipError(f"drop_regrouped: x must be [B, tokens, C], got {tuple(x_full.shape)}")
+    B, N, C = x_full.shape
+    cls = 1 if has_cls else 0
+    F, P = int(frames), plan.T
+    if N != cls + P * F or plan.n != B * F:
+        raise TomeHipError(f"drop_regrouped: x {tuple(x_full.shape)} does not hold {plan.n} groups of {P} tokens "
+                           f"({F} per clip) plus {cls} class token")
+    if x_full.device != plan.device:
+        raise TomeHipError("drop_regrouped: tensor and matching on different devices")
+    if torch.is_grad_enabled() and x_full.requires_grad:
+        raise TomeHipError("drop_regrouped: autograd through the HIP merge kernels is not implemented")
+    x_full = x_full if x_full.is_contiguous() else x_full.contiguous()
+    out = torch.empty((B, cls + (P - plan.r) * F, C), dtype=x_full.dtype, device=x_full.device)
+    with _on_device(x_full.device):
+        rc = lib().tome_drop_regrouped(x_full.data_ptr(), dtype_code(x_full, "x"), B, F, P, C, plan.r, cls,
+                                       plan.unm_idx.data_ptr(), out.data_ptr(), _stream(x_full.device))
+    _check(rc, "tome_drop_regrouped")
     return out
 
 

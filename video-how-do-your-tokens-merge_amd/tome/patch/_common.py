@@ -234,6 +234,26 @@ def reduce_drop(metric, x, info, r):
     return x
 
 
+def reduce_drop_regrouped(metric, x_full, info, r, frames: int):
+    """reduce_drop for the interleaved layouts: x_full [B, 1 + P*F, C] with the class token in front; the groups
+    are addressed in place by the kernel (tome_drop_regrouped) instead of regrouped by permuted copies
+    (timesformer.py:111-131, motionformer.py:172-193)."""
+    from .. import _abi
+    drop = bipartite_soft_matching_drop(metric, r, info["class_token"], info["distill_token"], info["mode"])
+    if isinstance(drop, tuple):
+        return x_full
+    plan = drop.plan
+    if info["trace_source"]:
+        if info["source"] is None:
+            info["source"] = torch.eye(plan.T, device=x_full.device)[None, ...].expand(plan.n, plan.T, plan.T)
+        info["source"] = drop(info["source"])
+    x_out = _abi.drop_regrouped(plan, x_full, frames, has_cls=True)
+    info["size"] = torch.ones((plan.n, plan.T - plan.r, 1), device=x_full.device)
+    if info["verbose"]:
+        print(f"Dropped {plan.T} to {plan.T - plan.r} tokens")
+    return x_out
+
+
 def reduce_hybrid(metric, x, info, r):
     merge, _ = bipartite_soft_matching_hybrid(metric, r, info["class_token"], info["distill_token"], info["mode"],
                                               info["threshold"])

@@ -87,7 +87,7 @@ def motionformer_merge(metric, x, _tome_info, num_frames):
 def motionformer_drop(metric, x, _tome_info, num_frames):
     r = _tome_info["r"].pop(0)
     if r > 0:
-        x = _ungroup(x[:, 0:1, :], C.reduce_drop(metric, _regroup(x, num_frames).contiguous(), _tome_info, r), num_frames)
+        x = C.reduce_drop_regrouped(metric, x, _tome_info, r, num_frames)  # groups addressed in place, no permuted copies
     return x
 
 

@@ -84,7 +84,7 @@ def timesformer_merge(metric, x, _tome_info, B, T, num_spatial_tokens):
 def timesformer_drop(metric, x, _tome_info, B, T, num_spatial_tokens):
     r = _tome_info["r"].pop(0)
     if r > 0:
-        x = _ungroup(x[:, 0:1, :], C.reduce_drop(metric, _regroup(x, B, T, num_spatial_tokens), _tome_info, r), B, T)
+        x = C.reduce_drop_regrouped(metric, x, _tome_info, r, T)  # groups addressed in place, no permuted copies
     return x
 
 
