@@ -38,6 +38,7 @@ HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md, chip-leve
 MFMA_F32_PEAK_TFLOPS = 157.3  # v_mfma_f32_32x32x2_f32 dense peak (same table)
 
 EMBED, HEADS, HEAD_DIM, LAYERS = 768, 12, 64, 12
+DEFAULT_BATCH = 128  # clips per GPU per step: 64 -> 128 is +4.7 % clips/s (GEMM / attention efficiency), 96 -> +3 %
 
 
 def parse():
@@ -45,7 +46,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=64, help="clips per GPU per step")
+    ap.add_argument("--batch", type=int, default=DEFAULT_BATCH, help="clips per GPU per step")
     ap.add_argument("--frames", type=int, default=16)
     ap.add_argument("--r", type=int, default=16)
     ap.add_argument("--cpu-clips", type=int, default=2, help="batch of the CPU baseline sample")
@@ -159,7 +160,7 @@ def measure_kernels(batch: int, t0: int, r: int, dev, reps: int = 10):
     return stats
 
 
-def roofline_of(stats):
+def roofline_of(stats, batch: int):
     """Roofline object of the kernel that takes the most device time per forward."""
     name = max(stats, key=lambda k: stats[k]["ms"])
     s = stats[name]
@@ -168,7 +169,9 @@ def roofline_of(stats):
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
         try:
-            traffic = json.load(open(tpath)).get(name)
+            tj = json.load(open(tpath))
+            # PMC bytes are per launch at the batch they were collected on: only quoted for that batch
+            traffic = tj.get(name) if tj.get("_batch", 64) == batch else None
         except Exception:
             traffic = None
     if name == "k_scores_rowmax":
@@ -314,7 +317,7 @@ def main():
         elif not args.no_roofline:
             with torch.no_grad():
                 stats = measure_kernels(B, t0_tokens, args.r, dev)
-            out["roofline"] = roofline_of(stats)
+            out["roofline"] = roofline_of(stats, B)
             out["merge_path_kernels"] = {
                 k: {"ms_per_step": round(v["ms"], 4), "launches": v["launches"],
                     "GB/s": round(v["bytes"] / (v["ms"] / 1e3) / 1e9, 1) if v["ms"] > 0 else None,

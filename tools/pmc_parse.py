@@ -33,7 +33,10 @@ def load(d):
 def main():
     fetch = load(sys.argv[1])
     write = load(sys.argv[2])
-    out = {"_units": "bytes per launch (mean over the launches of one 12-layer chain, batch 64)",
+    sys.path.insert(0, ROOT)
+    import bench
+    batch = int(sys.argv[3]) if len(sys.argv) > 3 else bench.DEFAULT_BATCH
+    out = {"_units": f"bytes per launch (mean over the launches of one 12-layer chain, batch {batch})",
            "_correction": "FETCH_SIZE KiB x2 (gfx950 wide-read under-count) + WRITE_SIZE KiB"}
     for k in fetch:
         f = sum(v for v, _ in fetch[k]) / len(fetch[k]) * 1024 * 2
@@ -45,6 +48,7 @@ def main():
             continue
         out[k] = {"fetch": round(f), "write": round(w), "total": round(f + w), "launches": len(fetch[k])}
     flat = {k: v["total"] for k, v in out.items() if isinstance(v, dict)}
+    flat["_batch"] = batch
     flat["_detail"] = out
     with open(os.path.join(ROOT, "profiles", "traffic.json"), "w") as fh:
         json.dump(flat, fh, indent=1)
