@@ -82,6 +82,8 @@ def parse_args(argv=None):
     ap = argparse.ArgumentParser(description="ToMe video models on MI355X (reference-compatible command line)")
     ap.add_argument("--cfg", dest="cfg_file", default=None)
     ap.add_argument("--dtype", choices=("fp32", "bf16", "fp16"), default="bf16")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay the forward from a HIP graph (hosts/graphed.py): static shapes, no launch cost")
     ap.add_argument("--opts", nargs=argparse.REMAINDER, default=[])
     ap.add_argument("--init_method", default="tcp://127.0.0.1:9999")  # accepted and ignored: torchrun env is used
     return ap.parse_args(argv)
@@ -162,7 +164,7 @@ def _input_shape(cfg, batch):
 
 
 @torch.no_grad()
-def perform_benchmark(model, cfg, dev, dtype: str, world: int = 1) -> dict:
+def perform_benchmark(model, cfg, dev, dtype: str, world: int = 1, graph: bool = False) -> dict:
     """slowfast/utils/model_benchmark.py:20-58: a fresh random batch per iteration, generated outside the event
     pair; the per-iteration times of all ranks are summed like `sum(du.all_gather_unaligned(time))`."""
     mb = cfg.MODEL_BENCHMARK
@@ -170,10 +172,14 @@ def perform_benchmark(model, cfg, dev, dtype: str, world: int = 1) -> dict:
     shape = _input_shape(cfg, cfg.TEST.BATCH_SIZE // max(1, world))
     start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     times = []
+    forward = model
+    if graph:
+        from .graphed import GraphedForward
+        forward = GraphedForward(model, [torch.rand(shape, device=dev).to(_DTYPES[dtype])])
     for _ in range(total):
         clip = [torch.rand(shape, device=dev).to(_DTYPES[dtype])]
         start.record()
-        model(clip)
+        forward(clip)
         end.record()
         torch.cuda.synchronize()
         t = torch.tensor([start.elapsed_time(end)], dtype=torch.float64, device=dev)
@@ -215,7 +221,7 @@ def main_benchmark(argv=None) -> dict:
     cfg = load_cfg(args.cfg_file, args.opts)
     model, dev, rank, world = _setup(cfg, args.dtype)
     apply_tome(model, cfg, with_threshold=False)
-    res = perform_benchmark(model, cfg, dev, args.dtype, world)
+    res = perform_benchmark(model, cfg, dev, args.dtype, world, graph=args.graph)
     if rank == 0:
         print(f"Average time per frame is {res['average_frame_time_s']}(s) after {res['iterations']} iterations")
         print(f"Average fps is {res['average_fps']}(im/s) after {res['iterations']} iterations")
