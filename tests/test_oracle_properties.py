@@ -1,0 +1,113 @@
+"""Property tests of the two CPU restatements against each other and against invariants of the path
+(hypothesis, CPU only): tests/oracle C restatement (fixed arithmetic order) vs oracle/torch_port.py (the
+reference's ATen op sequence) on random shapes, and size-independent properties the domain offers --
+token mass is conserved, r_eff follows merge.py:36-44, unmerge restores the layout, merging constant
+tokens leaves them constant, drop keeps rows verbatim."""
+import numpy as np
+import torch
+from hypothesis import HealthCheck, given, settings
+from hypothesis import strategies as st
+
+import oracle
+import synth
+from oracle import torch_port
+
+SET = settings(max_examples=40, deadline=None, suppress_health_check=[HealthCheck.too_slow])
+
+
+@st.composite
+def shapes(draw):
+    n = draw(st.integers(1, 3))
+    T = draw(st.integers(1, 70))
+    D = draw(st.sampled_from([1, 3, 8, 16, 64]))
+    C = draw(st.sampled_from([1, 5, 8, 32]))
+    r = draw(st.integers(0, 40))
+    cls = draw(st.booleans())
+    seed = draw(st.integers(0, 2 ** 31))
+    return n, T, D, C, r, cls, seed
+
+
+def _margins_ok(metric, plan, cls):
+    """fp64 re-evaluation: are the decisions of this matching separated by more than fp32 noise?  (The two
+    restatements sum in different orders; where margins are thinner than that the answer is not defined,
+    SURVEY 7.1 -- such draws are skipped.)"""
+    m = metric.astype(np.float64)
+    m = m / np.linalg.norm(m, axis=-1, keepdims=True)
+    a, b = m[:, ::2], m[:, 1::2]
+    s = a @ b.transpose(0, 2, 1)
+    if cls:
+        s[:, 0, :] = -np.inf
+    top = np.sort(s, axis=-1)
+    with np.errstate(invalid="ignore"):
+        thin = top.shape[-1] > 1 and np.any((top[..., -1] - top[..., -2])[np.isfinite(top[..., -1])] < 1e-5)
+    if thin:
+        return False
+    if False and np.any((top[..., -1] - top[..., -2])[np.isfinite(top[..., -1])] < 1e-5):
+        return False
+    nm = np.sort(top[..., -1], axis=-1)
+    nm = nm[np.isfinite(nm)]
+    return not np.any(np.diff(nm) < 1e-5)
+
+
+@SET
+@given(shapes())
+def test_c_oracle_equals_torch_port(shape):
+    n, T, D, C, r, cls, seed = shape
+    metric = synth.normal_like((n, T, D), seed)
+    x = synth.normal_like((n, T, C), seed + 1)
+    size = synth.small_ints((n, T, 1), seed + 2, 1, 6)
+    p_c = oracle.match(metric, r, cls)
+    p_t = torch_port.match(torch.from_numpy(metric), r, cls, False)
+    re = oracle.effective_r(T, r, cls)
+    assert re == max(0, min(r, (T - int(cls)) // 2))  # merge.py:36-44
+    if re == 0:
+        assert p_c is None and p_t is None
+        return
+    if not np.isfinite(metric / np.linalg.norm(metric, axis=-1, keepdims=True)).all() or not _margins_ok(metric, p_c, cls):
+        return
+    assert np.array_equal(p_c.src_idx, p_t.src_idx.numpy()) and np.array_equal(p_c.dst_idx, p_t.dst_idx.numpy())
+    assert np.array_equal(p_c.unm_idx, p_t.unm_idx.numpy())
+    xo_c, so_c = oracle.merge_wavg(p_c, x, size)
+    xo_t, so_t = torch_port.merge_wavg(p_t, torch.from_numpy(x), torch.from_numpy(size))
+    assert np.array_equal(xo_c, xo_t.numpy()) and np.array_equal(so_c, so_t.numpy())
+    for mode in ("sum", "mean", "amax"):
+        assert np.array_equal(oracle.merge(p_c, x, mode), torch_port.merge(p_t, torch.from_numpy(x), mode).numpy())
+
+
+@SET
+@given(shapes())
+def test_path_invariants(shape):
+    n, T, D, C, r, cls, seed = shape
+    metric = synth.normal_like((n, T, D), seed)
+    plan = oracle.match(metric, r, cls)
+    if plan is None:
+        return
+    re, T1 = plan.r, (T + 1) // 2
+    # every even token is either merged away or kept, exactly once; destinations are odd-token rows
+    both = np.concatenate([plan.src_idx[..., 0], plan.unm_idx[..., 0]], axis=1)
+    assert np.array_equal(np.sort(both, axis=1), np.tile(np.arange(T1), (n, 1)))
+    assert plan.dst_idx.min() >= 0 and plan.dst_idx.max() < T // 2
+    if cls:
+        assert np.all(plan.unm_idx[:, 0, 0] == 0) and np.all(np.diff(plan.unm_idx[..., 0], axis=1) > 0)
+    size = synth.small_ints((n, T, 1), seed + 2, 1, 6)
+    x = synth.normal_like((n, T, C), seed + 1)
+    xo, so = oracle.merge_wavg(plan, x, size)
+    assert xo.shape == (n, T - re, C) and np.array_equal(so.sum(axis=1), size.sum(axis=1))  # token mass
+    ones = np.ones((n, T, C), np.float32) * np.float32(3.25)
+    co, _ = oracle.merge_wavg(plan, ones, size)
+    assert np.array_equal(co, np.full_like(co, 3.25))  # weighted mean of a constant (small exact integers)
+    # sum-merge conserves the per-channel total (integers: exact)
+    xi = synth.small_ints((n, T, C), seed + 3, -4, 4)
+    assert np.array_equal(oracle.merge(plan, xi, "sum").sum(axis=1), xi.sum(axis=1))
+    # unmerge: kept tokens come back verbatim, a merged token gets its destination's value
+    un = oracle.unmerge(plan, oracle.merge(plan, x, "mean"))
+    assert un.shape == x.shape
+    for g in range(n):
+        kept = 2 * plan.unm_idx[g, :, 0]
+        assert np.array_equal(un[g, kept], x[g, kept])
+        assert np.array_equal(un[g, 2 * plan.src_idx[g, :, 0]], un[g, 2 * plan.dst_idx[g, :, 0] + 1])
+    # drop: rows are copies
+    d = oracle.drop(plan, x)
+    for g in range(n):
+        assert np.array_equal(d[g, :T1 - re], x[g, 2 * plan.unm_idx[g, :, 0]])
+        assert np.array_equal(d[g, T1 - re:], x[g, 1::2])
