@@ -11,7 +11,9 @@
 //   k_rank_select        folds the j-parts, stable descending rank by counting, writes src/dst/unm
 //   k_compact_unm        class-token case only: unm_idx in ascending row order (merge.py:71-73)
 // and of one merge (tome_merge_wavg[_regrouped] / tome_merge / tome_drop / tome_unmerge), tome_merge.h:
-//   k_merge_rows_fast    streaming waves (4 output rows each) + edge waves (rows that receive sources)
+//   k_merge_rows_fast    streaming waves (2-4 output rows each) + edge waves (rows that receive sources);
+//                        <LN>: residual add in front and LayerNorm behind fused in (tome_merge_wavg_ln)
+//   k_add_ln_rows        second residual + the next block's first LayerNorm (tome_add_layernorm)
 //   k_merge_rows / k_unmerge_rows   generic one-wave-per-row forms                        (HBM bound)
 //
 // The arithmetic contract (summation orders, tie rules) is the one written at the top of
