@@ -105,6 +105,29 @@ extern "C" int tome_profile_read(float *stage_ms, int max_stages) {
     return TOME_OK;
 }
 
+#ifdef TOME_DIAG_CLOCK
+// diagnostic build: in-kernel clock of the last k_scores_rowmax launch = sum(cycles) / sum(100 MHz ticks) over
+// its waves, in GHz; also the mean wave duration in microseconds
+extern "C" int tome_diag_clock(double *ghz, double *wave_us, int64_t *waves) {
+    static unsigned long long host[TOME_DIAG_SLOTS * 2];
+    if (hipMemcpyFromSymbol(host, HIP_SYMBOL(g_diag_stamps), sizeof(host)) != hipSuccess)
+        return fail(TOME_ELAUNCH, "tome_diag_clock: copy failed");
+    double cyc = 0, ticks = 0;
+    int64_t nw = 0;
+    for (int i = 0; i < TOME_DIAG_SLOTS; ++i)
+        if (host[2 * i + 1] > 0) {
+            cyc += (double)host[2 * i];
+            ticks += (double)host[2 * i + 1];
+            ++nw;
+        }
+    if (!nw) return fail(TOME_EINVAL, "tome_diag_clock: no stamps");
+    *ghz = cyc / ticks * 0.1;
+    *wave_us = ticks / nw * 0.01;
+    *waves = nw;
+    return TOME_OK;
+}
+#endif
+
 struct MatchWs {
     float *unitA, *unitB, *part_max;
     int *part_idx, *rank;

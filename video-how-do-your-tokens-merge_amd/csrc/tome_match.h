@@ -258,6 +258,14 @@ __device__ __forceinline__ void fold_tile(const f32x16 &acc, RowBest &rb, int jt
     }
 }
 
+#ifdef TOME_DIAG_CLOCK
+// Diagnostic build only (tools/diag_clock.py; never the shipped library): every wave stamps the shader clock
+// (s_memtime) and the 100 MHz wall counter (s_memrealtime) around its tile loop; the stamps go to a buffer of
+// their own that nothing else reads (MI355X_MICROARCH.md, DVFS give-back item 6).
+#define TOME_DIAG_SLOTS 65536
+__device__ unsigned long long g_diag_stamps[TOME_DIAG_SLOTS * 2];
+#endif
+
 template <bool ONE_CHUNK>
 __global__ __launch_bounds__(64) void k_scores_rowmax(const f32x4 *__restrict__ unitA,
                                                       const f32x4 *__restrict__ unitB, int n, int T1, int T2,
@@ -286,6 +294,9 @@ __global__ __launch_bounds__(64) void k_scores_rowmax(const f32x4 *__restrict__ 
 
     RowBest rb = {-INFINITY, 0};
     const int nstep = (jt1 - jt0) * nchunk;  // consecutive (tile, chunk) blocks of 512 float4
+#ifdef TOME_DIAG_CLOCK
+    const unsigned long long diag_c0 = __builtin_amdgcn_s_memtime(), diag_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
     if (nstep > 0) {
         f32x4 af[8], bt[8];
 #pragma unroll
@@ -321,6 +332,12 @@ __global__ __launch_bounds__(64) void k_scores_rowmax(const f32x4 *__restrict__ 
             jt += (cn == 0);
         }
     }
+#ifdef TOME_DIAG_CLOCK
+    if (lane == 0 && L < TOME_DIAG_SLOTS) {
+        g_diag_stamps[2 * L] = __builtin_amdgcn_s_memtime() - diag_c0;
+        g_diag_stamps[2 * L + 1] = __builtin_amdgcn_s_memrealtime() - diag_r0;
+    }
+#endif
     // the two lane halves hold the same A row, disjoint B rows: keep the larger, first index on ties
     {
         const float ob = __shfl_xor(rb.best, 32);
