@@ -664,3 +664,35 @@ def test_drop_regrouped_equals_rearranged(B, F, P, C, r, dtype):
     o_plan = oracle.match(metric, r)
     o = oracle.drop(o_plan, grouped)
     assert np.array_equal(d.float().cpu().numpy(), o)
+
+
+def test_more_than_2_31_elements():
+    """Maximum sizes: a token tensor with more than 2^31 elements (1800 x 1568 x 768 bf16, 4.3 GB) goes through
+    match + merge_wavg (+ fused LayerNorm / residual, + add_layernorm) with 64-bit addressing: the result equals
+    the same work done in three chunks of 600 groups, each below 2^31 elements."""
+    from tome import _abi
+    tm = _tome()
+    n, T, C, r = 1800, 1568, 768, 16
+    assert n * T * C > 2 ** 31
+    g = torch.Generator(device=DEV).manual_seed(5)
+    metric = torch.randn(n, T, 64, device=DEV, generator=g)
+    x = torch.randn(n, T, C, device=DEV, generator=g).bfloat16()
+    a = (0.1 * torch.randn(n, T, C, device=DEV, generator=g)).bfloat16()
+    w = torch.ones(C, device=DEV, dtype=torch.bfloat16)
+    b = torch.zeros(C, device=DEV, dtype=torch.bfloat16)
+    merge, _ = tm.bipartite_soft_matching(metric, r)
+    xo, so = tm.merge_wavg(merge, x)
+    fx, fy, fs = _abi.merge_wavg_ln(merge.plan, x, None, w, b, 1e-6, addend=a)
+    ax, ay = _abi.add_layernorm(x, a, w, b, 1e-6)
+    assert float(so.float().sum()) == n * T
+    for lo in range(0, n, 600):
+        sl = slice(lo, lo + 600)
+        m2, _ = tm.bipartite_soft_matching(metric[sl].contiguous(), r)
+        for name in ("src_idx", "dst_idx", "unm_idx"):
+            assert torch.equal(getattr(m2.plan, name), getattr(merge.plan, name)[sl]), name
+        xo2, so2 = tm.merge_wavg(m2, x[sl].contiguous())
+        assert torch.equal(xo2, xo[sl]) and torch.equal(so2, so[sl])
+        gx, gy, gs = _abi.merge_wavg_ln(m2.plan, x[sl].contiguous(), None, w, b, 1e-6, addend=a[sl].contiguous())
+        assert torch.equal(gx, fx[sl]) and torch.equal(gy, fy[sl]) and torch.equal(gs, fs[sl])
+        bx, by = _abi.add_layernorm(x[sl].contiguous(), a[sl].contiguous(), w, b, 1e-6)
+        assert torch.equal(bx, ax[sl]) and torch.equal(by, ay[sl])
