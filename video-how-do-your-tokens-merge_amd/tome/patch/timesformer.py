@@ -21,23 +21,40 @@ def _block_forward(self, x, B, T, W):
     P = (x.size(1) - 1) // T  # spatial tokens per frame right now (H and W mean nothing after merging)
     m = x.size(2)
     # temporal attention over the T copies of every spatial token
-    xt = x[:, 1:, :]
-    rt = self.drop_path(self.temporal_attn(self.temporal_norm1(xt.reshape(B * P, T, m)))).reshape(B, P * T, m)
-    xt = xt + self.temporal_fc(rt)
-    # spatial attention per frame, class token replicated into every frame
+    rt = self.drop_path(self.temporal_attn(self.temporal_norm1(x[:, 1:, :].reshape(B * P, T, m)))).reshape(B, P * T, m)
     cls0 = x[:, :1, :]
-    cls = cls0.expand(B, T, m).reshape(B * T, 1, m)
-    xs = xt.reshape(B, P, T, m).transpose(1, 2).reshape(B * T, P, m)
-    rs, metric = self.attn(self.norm1(torch.cat((cls, xs), 1)), attn_size)
+    if torch.is_grad_enabled() and x.requires_grad:
+        # the reference's op sequence (differentiable): add, transpose, three cats
+        xt = x[:, 1:, :] + self.temporal_fc(rt)
+        x1 = torch.cat((cls0, xt), 1)
+        xs_in = torch.cat((cls0.expand(B, T, m).reshape(B * T, 1, m),
+                           xt.reshape(B, P, T, m).transpose(1, 2).reshape(B * T, P, m)), 1)
+    else:
+        # same values without the cat passes: the sum is written straight behind the class token, and
+        # 'b (p t) -> (b t) p' is ONE strided copy into the buffer that already holds the replicated class tokens
+        x1 = torch.empty_like(x)
+        x1[:, :1, :] = cls0
+        xt = torch.add(x[:, 1:, :], self.temporal_fc(rt), out=x1[:, 1:, :])
+        xs_in = torch.empty((B * T, 1 + P, m), dtype=x.dtype, device=x.device)
+        xs_in[:, 0, :] = cls0.expand(B, T, m).reshape(B * T, m)
+        xs_in.view(B, T, 1 + P, m)[:, :, 1:, :].copy_(xt.reshape(B, P, T, m).transpose(1, 2))
+    # spatial attention per frame, class token replicated into every frame
+    rs, metric = self.attn(self.norm1(xs_in), attn_size)
     rs = self.drop_path(rs)
     cls_new = rs[:, 0, :].reshape(B, T, m).mean(1, keepdim=True)  # class token averaged over frames
-    rs = rs[:, 1:, :].reshape(B, T, P, m).transpose(1, 2).reshape(B, P * T, m)
+    rs_body = rs.reshape(B, T, 1 + P, m)[:, :, 1:, :].transpose(1, 2)  # '(b t) p -> b p t', still a view
+    if torch.is_grad_enabled() and rs.requires_grad:
+        res = torch.cat((cls_new, rs_body.reshape(B, P * T, m)), 1)
+    else:
+        res = torch.empty_like(x1)  # the second residual, assembled by one strided copy
+        res[:, :1, :] = cls_new
+        res[:, 1:, :].view(B, P, T, m).copy_(rs_body)
     # x = cat(cls0, xt) + cat(cls_new, rs); merge per frame; norm2 -- one kernel when the layer merges 16-bit
     # tokens (tome_merge_wavg_regrouped_ln), the reference's steps otherwise
     x, y = C.merge_then_norm_regrouped(
-        metric, torch.cat((cls0, xt), 1), info, self.norm2,
+        metric, x1, info, self.norm2,
         lambda z: self.reduction_function(metric, z, info, B, T, P), self.reduction_function is timesformer_merge, T,
-        residual=torch.cat((cls_new, rs), 1))
+        residual=res)
     return x + self.drop_path(self.mlp(y))
 
 
