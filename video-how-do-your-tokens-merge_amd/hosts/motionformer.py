@@ -77,12 +77,14 @@ def trajectory_attention(mod, x, P, F, approx="none", size=None):
     q2 = rearrange(mod.proj_q(y_diag), "b s (h d) -> b h s d", h=h) * mod.scale
     k2, v2 = mod.proj_kv(y).chunk(2, dim=-1)
     k2, v2 = (rearrange(t, "b s f (h d) -> b h s f d", f=F, h=h) for t in (k2, v2))
-    tattn = torch.einsum("b h s d, b h s f d -> b h s f", q2, k2).softmax(dim=-1)
+    # F = 8 logits per trajectory: a broadcast multiply + reduction streams k2 once; as the batched
+    # [1 x d] @ [d x F] products the einsum form lowers to, it is the slowest kernel of the model on MI355X
+    tattn = (k2 * q2.unsqueeze(-2)).sum(dim=-1).softmax(dim=-1)
     if mod.use_original_code:
         val = rearrange(y, "b s f (h d) -> b h s f d", f=F, h=h)
     else:
         val = v2
-    out = rearrange(torch.einsum("b h s f, b h s f d -> b h s d", tattn, val), "b h s d -> b s (h d)")
+    out = rearrange((val * tattn.unsqueeze(-1)).sum(dim=-2), "b h s d -> b s (h d)")  # same remark
     out = mod.proj_drop(mod.proj(torch.cat((cls_out, out), dim=1)))
     return out, tattn, k_
 
