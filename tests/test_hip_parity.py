@@ -296,6 +296,35 @@ def test_errors_are_loud():
         merge(torch.randn(2, 15, 8, device=DEV))  # wrong token count
     with pytest.raises(TomeHipError):
         merge(torch.randn(2, 16, 8, device=DEV), mode="median")
+    # more misuse that must be refused on the host, never reach a kernel with wrong shapes
+    from tome import _abi
+    with pytest.raises(TomeHipError):
+        merge(torch.randn(3, 16, 8, device=DEV))  # wrong number of groups
+    with pytest.raises(TomeHipError):
+        merge(torch.randn(2, 16, device=DEV))  # not [n, T, C]
+    with pytest.raises(TomeHipError):
+        merge(torch.randint(0, 5, (2, 16, 8), device=DEV))  # integer tokens
+    with pytest.raises(TomeHipError):
+        tm.merge_wavg(merge, torch.randn(2, 16, 8, device=DEV), torch.ones(2, 15, 1, device=DEV))  # size shape
+    with pytest.raises(TomeHipError):
+        tm.merge_wavg(merge, torch.randn(2, 16, 8, device=DEV, requires_grad=True))  # autograd: inference path only
+    with pytest.raises(TomeHipError):
+        tm.bipartite_soft_matching(torch.randn(2, 16, device=DEV), 4)  # metric not [n, T, D]
+    with pytest.raises(TomeHipError):
+        tm.bipartite_soft_matching(torch.randn(2, 16, 8, device=DEV).double(), 4)  # fp64 keys
+    w = torch.ones(8, device=DEV, dtype=torch.bfloat16)
+    xb = torch.randn(2, 16, 8, device=DEV).bfloat16()
+    with pytest.raises(TomeHipError):
+        _abi.merge_wavg_ln(merge.plan, xb, None, w, w, 1e-6, addend=xb[:, :8])  # addend shape
+    with pytest.raises(TomeHipError):
+        _abi.merge_wavg_regrouped(merge.plan, torch.randn(1, 1 + 16 * 3, 8, device=DEV), None, 3)  # 2 groups != 1*3
+    with pytest.raises(TomeHipError):
+        _abi.drop_regrouped(merge.plan, torch.randn(1, 16 * 2, 8, device=DEV), 2)  # class token missing
+    with pytest.raises(TomeHipError):
+        _abi.add_layernorm(xb, xb[:, :, :4], w, w, 1e-6)
+    # non-contiguous inputs are accepted (made contiguous), with the same result
+    xt = torch.randn(2, 8, 16, device=DEV).transpose(1, 2)
+    assert torch.equal(merge(xt), merge(xt.contiguous()))
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
