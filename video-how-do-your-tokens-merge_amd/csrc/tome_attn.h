@@ -1,0 +1,263 @@
+// tome_attn.h -- proportional attention of the ToMe patches as one gfx950 kernel.
+//
+//   attn = softmax(q k^T * scale + log(size)[keys])  ;  out = attn v
+//   (ToMeAttention.forward: tome/patch/videomae.py:55-66, vivit.py:95-113; timesformer.py:66-78 adds the bias to
+//    the non-class block of the logits only)
+//
+// PyTorch-ROCm's fused attention leaves its fast path as soon as a bias tensor is passed (measured on MI355X:
+// 1037 us with a [B,1,1,N] bias vs 560 us without at 8 x 12 x 3137 x 64); here the per-key bias is one fp32
+// value per key added in the softmax, so proportional attention costs what plain attention costs.
+//
+// Structure (head dim 64, 16-bit q/k/v, fp32 softmax and accumulation):
+//   * workgroup = 4 waves = 128 queries of one (batch, head); wave w owns queries 32w .. 32w+31.
+//   * keys/values stream through LDS in tiles of 64 keys (register-staged: the next tile's global loads are
+//     issued before the current tile's math and written to LDS behind it).
+//   * S^T = K Q^T on v_mfma_f32_32x32x16_bf16 (A = K rows from LDS, B = this wave's Q fragment in registers):
+//     accumulator register v of lane l holds key (v&3) + 8*(v>>2) + 4*(l>>5) (+32 per key block) of query l&31,
+//     so a query's scores are lane-local (plus the partner lane l^32): max / sum / rescale need no LDS.
+//   * P^T (bf16) is the B operand of O^T += V^T P^T as it sits in those registers; V^T fragments come from the
+//     row-major V tile through ds_read_b64_tr_b16 (4 consecutive keys of one channel per lane).
+//   * O^T accumulator: all 32 registers of a lane belong to its query -> the online-softmax rescale is a
+//     lane-local multiply.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "tome_common.h"
+
+#define ATT_D 64        // head dim
+#define ATT_BM 128      // queries per workgroup
+#define ATT_BN 64       // keys per tile
+#define ATT_KS 72       // K tile row stride in elements (144 B: conflict-free ds_read_b128 over 16 rows)
+#define ATT_VS 96       // V tile row stride in elements (192 B: conflict-free ds_read_b64_tr_b16 over 4 rows)
+
+typedef float att_f32x16 __attribute__((ext_vector_type(16)));
+typedef short att_s16x4 __attribute__((ext_vector_type(4)));
+typedef short att_s16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 att_bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 att_f16x8 __attribute__((ext_vector_type(8)));
+
+struct AttnArgs {
+    const void *q, *k, *v;
+    void *out;
+    int64_t q_sb, q_sh, q_sn, k_sb, k_sh, k_sn, v_sb, v_sh, v_sn;  // element strides: batch, head, token
+    int64_t o_sb, o_sn;                                            // out [B, N, H*64]
+    const float *log_size;                                         // NULL or [B, N - bias_skip] fp32
+    int64_t ls_sb;
+    int B, H, N;
+    float scale;
+    int bias_skip;  // 1: TimeSformer form -- key 0 and query 0 carry no bias, log_size[j-1] belongs to key j
+};
+
+template <typename TX> struct AttMfma;
+template <> struct AttMfma<bf16_t> {
+    static __device__ __forceinline__ att_f32x16 run(att_s16x8 a, att_s16x8 b, att_f32x16 c) {
+        att_bf16x8 x, y;
+        __builtin_memcpy(&x, &a, 16);
+        __builtin_memcpy(&y, &b, 16);
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, c, 0, 0, 0);
+    }
+};
+template <> struct AttMfma<f16_t> {
+    static __device__ __forceinline__ att_f32x16 run(att_s16x8 a, att_s16x8 b, att_f32x16 c) {
+        att_f16x8 x, y;
+        __builtin_memcpy(&x, &a, 16);
+        __builtin_memcpy(&y, &b, 16);
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(x, y, c, 0, 0, 0);
+    }
+};
+
+template <typename TX> __device__ __forceinline__ short att_bits(float f) {
+    const TX t = from_f32<TX>(f);
+    short s;
+    __builtin_memcpy(&s, &t, 2);
+    return s;
+}
+
+template <typename TX>
+__global__ __launch_bounds__(256) void k_prop_attention(AttnArgs a) {
+    __shared__ __attribute__((aligned(16))) short lds_k[ATT_BN * ATT_KS];
+    __shared__ __attribute__((aligned(16))) short lds_v[ATT_BN * ATT_VS];
+    __shared__ __attribute__((aligned(16))) float lds_bias[ATT_BN];  // log(size)*log2(e) per key, -inf out of range
+    __shared__ __attribute__((aligned(16))) float lds_mask[ATT_BN];  // 0 in range, -inf out of range
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int col = lane & 31, hf = lane >> 5;
+    const int qblocks = (a.N + ATT_BM - 1) / ATT_BM;
+    // XCD-aware mapping: the query blocks of one (batch, head) stream the same K/V -> same XCD (ids congruent mod 8)
+    const int L = blockIdx.x;
+    const int xcd = L & 7, s = L >> 3;
+    const int bh = (s / qblocks) * 8 + xcd;
+    if (bh >= a.B * a.H) return;
+    const int qb = s % qblocks;
+    const int b = bh / a.H, h = bh % a.H;
+
+    const short *qp = reinterpret_cast<const short *>(a.q) + b * a.q_sb + h * a.q_sh;
+    const short *kp = reinterpret_cast<const short *>(a.k) + b * a.k_sb + h * a.k_sh;
+    const short *vp = reinterpret_cast<const short *>(a.v) + b * a.v_sb + h * a.v_sh;
+    const float *lsp = a.log_size ? a.log_size + b * a.ls_sb : nullptr;
+
+    // this lane's query and its Q fragment: B operand of S^T = K Q^T (k = channel): 4 steps x 8 channels
+    const int qrow = qb * ATT_BM + wave * 32 + col;
+    const int qload = qrow < a.N ? qrow : a.N - 1;
+    att_s16x8 qf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+        qf[ks] = *reinterpret_cast<const att_s16x8 *>(qp + (int64_t)qload * a.q_sn + 16 * ks + 8 * hf);
+    const bool unbiased_query = a.bias_skip && qrow == 0;
+    const float *bias_row = unbiased_query ? lds_mask : lds_bias;
+
+    const float LOG2E = 1.4426950408889634f;
+    const float sl = a.scale * LOG2E;
+    att_f32x16 o0, o1;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) o0[v] = o1[v] = 0.0f;
+    float m_run = -INFINITY, l_run = 0.0f;
+
+    const int ntiles = (a.N + ATT_BN - 1) / ATT_BN;
+    // staging: thread t moves chunks c = t and t + 256 (16 B each) of the 64 x 64 K and V tiles
+    const int r0 = tid >> 3, c0 = tid & 7;  // rows r0 and r0 + 32, 16-byte column c0
+    uint4 kreg[2], vreg[2];
+    float breg = 0.0f, mreg = 0.0f;
+    auto stage_load = [&](int t) {
+        const int key0 = t * ATT_BN;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int key = key0 + r0 + 32 * i;
+            if (key < a.N) {
+                kreg[i] = *reinterpret_cast<const uint4 *>(kp + (int64_t)key * a.k_sn + 8 * c0);
+                vreg[i] = *reinterpret_cast<const uint4 *>(vp + (int64_t)key * a.v_sn + 8 * c0);
+            } else {
+                kreg[i] = uint4{0, 0, 0, 0};
+                vreg[i] = uint4{0, 0, 0, 0};  // zeros: p = 0 times a finite value
+            }
+        }
+        if (tid < ATT_BN) {
+            const int key = key0 + tid;
+            const bool in = key < a.N;
+            float bv = 0.0f;
+            if (in && lsp && key >= a.bias_skip) bv = lsp[key - a.bias_skip] * LOG2E;
+            breg = in ? bv : -INFINITY;
+            mreg = in ? 0.0f : -INFINITY;
+        }
+    };
+    auto stage_write = [&]() {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            *reinterpret_cast<uint4 *>(lds_k + (r0 + 32 * i) * ATT_KS + 8 * c0) = kreg[i];
+            *reinterpret_cast<uint4 *>(lds_v + (r0 + 32 * i) * ATT_VS + 8 * c0) = vreg[i];
+        }
+        if (tid < ATT_BN) {
+            lds_bias[tid] = breg;
+            lds_mask[tid] = mreg;
+        }
+    };
+
+    stage_load(0);
+    stage_write();
+    __syncthreads();
+
+    for (int t = 0; t < ntiles; ++t) {
+        if (t + 1 < ntiles) stage_load(t + 1);
+
+        // ---- S^T = K Q^T : two blocks of 32 keys, four channel steps
+        att_f32x16 s0, s1;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) s0[v] = s1[v] = 0.0f;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const att_s16x8 k0 = *reinterpret_cast<const att_s16x8 *>(lds_k + col * ATT_KS + 16 * ks + 8 * hf);
+            const att_s16x8 k1 = *reinterpret_cast<const att_s16x8 *>(lds_k + (32 + col) * ATT_KS + 16 * ks + 8 * hf);
+            s0 = AttMfma<TX>::run(k0, qf[ks], s0);
+            s1 = AttMfma<TX>::run(k1, qf[ks], s1);
+        }
+        // ---- logits in base 2 with the per-key bias; register v <-> key (v&3) + 8*(v>>2) + 4*hf (+32)
+        float mt = -INFINITY;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 b0 = *reinterpret_cast<const float4 *>(bias_row + 8 * g + 4 * hf);
+            const float4 b1 = *reinterpret_cast<const float4 *>(bias_row + 32 + 8 * g + 4 * hf);
+            s0[4 * g + 0] = __builtin_fmaf(s0[4 * g + 0], sl, b0.x);
+            s0[4 * g + 1] = __builtin_fmaf(s0[4 * g + 1], sl, b0.y);
+            s0[4 * g + 2] = __builtin_fmaf(s0[4 * g + 2], sl, b0.z);
+            s0[4 * g + 3] = __builtin_fmaf(s0[4 * g + 3], sl, b0.w);
+            s1[4 * g + 0] = __builtin_fmaf(s1[4 * g + 0], sl, b1.x);
+            s1[4 * g + 1] = __builtin_fmaf(s1[4 * g + 1], sl, b1.y);
+            s1[4 * g + 2] = __builtin_fmaf(s1[4 * g + 2], sl, b1.z);
+            s1[4 * g + 3] = __builtin_fmaf(s1[4 * g + 3], sl, b1.w);
+        }
+#pragma unroll
+        for (int v = 0; v < 16; ++v) mt = fmaxf(mt, fmaxf(s0[v], s1[v]));
+        mt = fmaxf(mt, __shfl_xor(mt, 32));
+        const float m_new = fmaxf(m_run, mt);  // finite: every tile holds at least one key in range
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        float lsum = 0.0f;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            s0[v] = __builtin_amdgcn_exp2f(s0[v] - m_new);
+            s1[v] = __builtin_amdgcn_exp2f(s1[v] - m_new);
+            lsum += s0[v] + s1[v];
+        }
+        l_run = l_run * alpha + lsum;
+        m_run = m_new;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            o0[v] *= alpha;
+            o1[v] *= alpha;
+        }
+        // ---- O^T += V^T P^T : step (kb, p) contracts the 16 key slots {8*hf' + e}: slot e of half hf' is key
+        //      32*kb + 16*p + 8*(e>>2) + 4*hf' + (e&3) -- the keys a lane already holds in registers 8p .. 8p+7
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                att_s16x8 pf;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) pf[e] = att_bits<TX>(kb == 0 ? s0[8 * p + e] : s1[8 * p + e]);
+                // V^T fragments: channel row = col (+32), key slots as above; one transposed read delivers the 4
+                // consecutive keys of one channel: lane i = 4*rq + pc of a 16-lane group addresses row rq, columns
+                // 4*pc .. 4*pc+3 of the 4 x 16 block and receives column i
+                const int grp = (lane >> 4) & 1;          // which 16 channels of this half's 32
+                const int li = lane & 15, rq = li >> 2, pc = li & 3;
+                const int keyA = 32 * kb + 16 * p + 4 * hf + rq;  // e < 4
+                const short *va = lds_v + keyA * ATT_VS + 16 * grp + 4 * pc;
+                typedef __attribute__((address_space(3))) att_s16x4 *lds_s16x4_p;
+                const att_s16x4 a0lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(va));
+                const att_s16x4 a0hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(va + 8 * ATT_VS));
+                const att_s16x4 a1lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(va + 32));
+                const att_s16x4 a1hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(va + 8 * ATT_VS + 32));
+                att_s16x8 vf0, vf1;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    vf0[e] = a0lo[e];
+                    vf0[4 + e] = a0hi[e];
+                    vf1[e] = a1lo[e];
+                    vf1[4 + e] = a1hi[e];
+                }
+                o0 = AttMfma<TX>::run(vf0, pf, o0);
+                o1 = AttMfma<TX>::run(vf1, pf, o1);
+            }
+        }
+        __syncthreads();  // every wave is done with tile t
+        if (t + 1 < ntiles) stage_write();
+        __syncthreads();
+    }
+
+    // ---- out[b, q, h*64 + d] = O^T[d][q] / l ; register v <-> channel (v&3) + 8*(v>>2) + 4*hf (+32)
+    const float l_tot = l_run + __shfl_xor(l_run, 32);
+    const float inv = 1.0f / l_tot;
+    if (qrow < a.N) {
+        short *op = reinterpret_cast<short *>(a.out) + b * a.o_sb + (int64_t)qrow * a.o_sn + h * ATT_D;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            att_s16x4 w0, w1;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                w0[e] = att_bits<TX>(o0[4 * g + e] * inv);
+                w1[e] = att_bits<TX>(o1[4 * g + e] * inv);
+            }
+            *reinterpret_cast<att_s16x4 *>(op + 8 * g + 4 * hf) = w0;
+            *reinterpret_cast<att_s16x4 *>(op + 32 + 8 * g + 4 * hf) = w1;
+        }
+    }
+}

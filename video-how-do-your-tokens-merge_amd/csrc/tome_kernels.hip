@@ -29,6 +29,7 @@
 #include "tome_common.h"
 #include "tome_match.h"
 #include "tome_merge.h"
+#include "tome_attn.h"
 
 // ------------------------------------------------------------------------------------------------
 // host side: argument checks, workspace carving, launches
@@ -649,6 +650,41 @@ extern "C" int tome_drop_regrouped(const void *x, int dtype, int64_t B, int64_t 
     if (dtype == TOME_F16) DROPR(f16_t);
 #undef DROPR
     return fail(TOME_EINVAL, "tome_drop_regrouped: dtype %d", dtype);
+}
+
+extern "C" int tome_prop_attention(const void *q, const void *k, const void *v, int dtype, int64_t B, int64_t H,
+                                   int64_t N, int64_t D, const int64_t *q_strides, const int64_t *k_strides,
+                                   const int64_t *v_strides, const float *log_size, int64_t log_size_stride,
+                                   int bias_skip, float scale, void *out, tome_stream_t stream) {
+    if (!q || !k || !v || !out || !q_strides || !k_strides || !v_strides || B <= 0 || H <= 0 || N <= 0)
+        return fail(TOME_EINVAL, "tome_prop_attention: bad shape/pointer");
+    if (D != ATT_D) return fail(TOME_EINVAL, "tome_prop_attention: head dim %lld (only 64)", (long long)D);
+    if (dtype != TOME_BF16 && dtype != TOME_F16) return fail(TOME_EINVAL, "tome_prop_attention: 16-bit q/k/v only");
+    if (bias_skip != 0 && bias_skip != 1) return fail(TOME_EINVAL, "tome_prop_attention: bias_skip %d", bias_skip);
+    if (B * H > 0x7fffffffLL / 64 || N > 0x7fffffffLL / 4) return fail(TOME_EINVAL, "tome_prop_attention: too large");
+    const int64_t *ss[3] = {q_strides, k_strides, v_strides};
+    const void *pp[3] = {q, k, v};
+    for (int i = 0; i < 3; ++i) {
+        if (!aligned16(pp[i]) || ss[i][0] % 8 || ss[i][1] % 8 || ss[i][2] % 8 || ss[i][2] < D)
+            return fail(TOME_EINVAL, "tome_prop_attention: q/k/v rows must be 16-byte aligned (strides %% 8 == 0)");
+    }
+    if (!aligned16(out)) return fail(TOME_EINVAL, "tome_prop_attention: out not 16-byte aligned");
+    AttnArgs a;
+    a.q = q; a.k = k; a.v = v; a.out = out;
+    a.q_sb = q_strides[0]; a.q_sh = q_strides[1]; a.q_sn = q_strides[2];
+    a.k_sb = k_strides[0]; a.k_sh = k_strides[1]; a.k_sn = k_strides[2];
+    a.v_sb = v_strides[0]; a.v_sh = v_strides[1]; a.v_sn = v_strides[2];
+    a.o_sb = N * H * D; a.o_sn = H * D;
+    a.log_size = log_size; a.ls_sb = log_size_stride;
+    a.B = (int)B; a.H = (int)H; a.N = (int)N; a.scale = scale; a.bias_skip = bias_skip;
+    const int64_t qblocks = (N + ATT_BM - 1) / ATT_BM;
+    const int64_t bh8 = (B * H + 7) / 8 * 8;
+    if (bh8 * qblocks > 0x7fffffffLL) return fail(TOME_EINVAL, "tome_prop_attention: grid too large");
+    const dim3 grid((unsigned)(bh8 * qblocks));
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == TOME_BF16) hipLaunchKernelGGL(k_prop_attention<bf16_t>, grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(k_prop_attention<f16_t>, grid, dim3(256), 0, st, a);
+    return check_launch("k_prop_attention");
 }
 
 template <typename TX>

@@ -18,7 +18,8 @@ SYMBOLS = (
     "tome_abi_version", "tome_last_error", "tome_effective_r", "tome_match_workspace_bytes", "tome_match",
     "tome_match_keys",
     "tome_match_scores", "tome_edge_keep", "tome_merge_wavg", "tome_merge_wavg_ln", "tome_merge_wavg_regrouped",
-    "tome_merge_wavg_regrouped_ln", "tome_add_layernorm", "tome_merge", "tome_drop", "tome_drop_regrouped",
+    "tome_merge_wavg_regrouped_ln", "tome_add_layernorm", "tome_prop_attention", "tome_merge", "tome_drop",
+    "tome_drop_regrouped",
     "tome_unmerge",
     "tome_profile_enable", "tome_profile_read",
 )
@@ -78,6 +79,8 @@ def lib() -> ctypes.CDLL:
     L.tome_add_layernorm.argtypes = [vp, vp, i32, i64, i64, vp, vp, ctypes.c_float, vp, vp, vp]
     L.tome_merge.restype = i32
     L.tome_merge.argtypes = [vp, i32, i64, i64, i64, i64, vp, vp, vp, i32, i32, vp, vp, vp]
+    L.tome_prop_attention.restype = i32
+    L.tome_prop_attention.argtypes = [vp, vp, vp, i32, i64, i64, i64, i64, vp, vp, vp, vp, i64, i32, ctypes.c_float, vp, vp]
     L.tome_drop_regrouped.restype = i32
     L.tome_drop_regrouped.argtypes = [vp, i32, i64, i64, i64, i64, i64, i32, vp, vp, vp]
     L.tome_drop.restype = i32
@@ -482,6 +485,42 @@ def drop(plan: MatchPlan, x: torch.Tensor) -> torch.Tensor:
         rc = lib().tome_drop(x.data_ptr(), dtype_code(x, "x"), n, T, C, plan.r, plan.unm_idx.data_ptr(),
                              int(plan.distill_token), out.data_ptr(), _stream(x.device))
     _check(rc, "tome_drop")
+    return out
+
+
+def prop_attention_ok(q: torch.Tensor) -> bool:
+    """Can tome_prop_attention take these heads?  ([B, H, N, 64] views of 16-bit device tensors, rows 16-byte aligned.)"""
+    return (q.is_cuda and q.dim() == 4 and q.shape[-1] == 64 and q.dtype in (torch.bfloat16, torch.float16)
+            and q.stride(-1) == 1 and all(s % 8 == 0 for s in q.stride()[:3]) and q.data_ptr() % 16 == 0
+            and not (torch.is_grad_enabled() and q.requires_grad))
+
+
+def prop_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, size: Optional[torch.Tensor], scale: float,
+                   bias_skip: bool = False) -> torch.Tensor:
+    """softmax(q k^T * scale + log(size) on the keys) v for [B, H, N, 64] head views (any strides with contiguous
+    channels: the slices of a qkv buffer are read in place); returns [B, N, H*64].  `size` is the token size
+    tensor [B, N(-1), 1] (its log comes from the merge kernel when that emitted it) or None.  bias_skip: the
+    TimeSformer form -- key 0 / query 0 unbiased, size describes keys 1..N-1."""
+    for t, name in ((q, "q"), (k, "k"), (v, "v")):
+        require_device(t, f"prop_attention({name})")
+        if not prop_attention_ok(t) or t.shape != q.shape or t.dtype != q.dtype or t.device != q.device:
+            raise TomeHipError(f"prop_attention: {name} must be a [B, H, N, 64] 16-bit view with 16-byte aligned rows, "
+                               f"got {tuple(t.shape)} {t.dtype} strides {t.stride()}")
+    B, H, N, D = q.shape
+    log = None
+    if size is not None:
+        want = (B, N - (1 if bias_skip else 0), 1)
+        if tuple(size.shape) != want:
+            raise TomeHipError(f"prop_attention: size must be {want}, got {tuple(size.shape)}")
+        log = log_of_size(size).reshape(B, -1).float().contiguous()
+    out = torch.empty((B, N, H * D), dtype=q.dtype, device=q.device)
+    strides = [(ctypes.c_int64 * 3)(*t.stride()[:3]) for t in (q, k, v)]
+    with _on_device(q.device):
+        rc = lib().tome_prop_attention(q.data_ptr(), k.data_ptr(), v.data_ptr(), dtype_code(q, "q"), B, H, N, D,
+                                       strides[0], strides[1], strides[2], _ptr(log),
+                                       0 if log is None else log.stride(0), 1 if bias_skip else 0, float(scale),
+                                       out.data_ptr(), _stream(q.device))
+    _check(rc, "tome_prop_attention")
     return out
 
 

@@ -19,6 +19,7 @@ _SUBCLASSES: Dict[Tuple[type, str], type] = {}
 _FUSE_LN = os.environ.get("TOME_FUSE_LN", "1") != "0"  # measurement switch: 0 = merge and LayerNorm as two steps
 _FUSE_ADD = os.environ.get("TOME_FUSE_ADD", "1") != "0"  # measurement switch: 0 = residual add as its own pass
 _FUSE_NEXT = os.environ.get("TOME_FUSE_NEXT", "1") != "0"  # 0 = second residual and the next block's norm1 separate
+_ATTN_KERNEL = os.environ.get("TOME_ATTN_KERNEL", "1") != "0"  # 0 = the framework's fused attention (+ bias tensor)
 
 
 def swizzle(module: torch.nn.Module, tag: str, methods: dict) -> None:
@@ -72,6 +73,28 @@ def wrap_model_forward(model_wrapper: torch.nn.Module, blocks_of: Callable) -> N
 
     sub = type("ToMeVisionTransformer", (base,), {"forward": forward, "_tome_tag": "ToMeVisionTransformer"})
     model_wrapper.__class__ = sub
+
+
+def attention(q, k, v, size, scale: float, dropout_p: float = 0.0, bias_skip: bool = False):
+    """softmax(q k^T * scale + log(size)) v for [B, H, N, hd] head views; returns [B, N, H*hd].
+    16-bit heads of width 64 without dropout go through tome_prop_attention (the size bias is one value per key
+    inside the kernel, q/k/v are read in place from the projection's output); everything else through the
+    framework's attention with the bias tensor the reference builds (videomae.py:62-63, timesformer.py:73-74)."""
+    from .. import _abi
+    B, H, N, hd = q.shape
+    if (_ATTN_KERNEL and dropout_p == 0.0 and _abi.prop_attention_ok(q) and _abi.prop_attention_ok(k)
+            and _abi.prop_attention_ok(v)):
+        return _abi.prop_attention(q, k, v, size, scale, bias_skip=bias_skip)
+    bias = None
+    if size is not None:
+        log = _abi.log_of_size(size)[:, None, None, :, 0].to(q.dtype)
+        if bias_skip:
+            bias = torch.zeros(B, 1, N, N, dtype=q.dtype, device=q.device)
+            bias[:, :, 1:, 1:] = log
+        else:
+            bias = log
+    out = torch.nn.functional.scaled_dot_product_attention(q, k, v, attn_mask=bias, dropout_p=dropout_p, scale=scale)
+    return out.transpose(1, 2).reshape(B, N, H * hd)
 
 
 def pick_reduction(mode: str, merge_fn, drop_fn, hybrid_fn):

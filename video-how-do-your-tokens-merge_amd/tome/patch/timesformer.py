@@ -4,10 +4,8 @@ frame loses the same r tokens so the frame groups stay rectangular."""
 from __future__ import annotations
 
 import torch
-import torch.nn.functional as F
 
 from . import _common as C
-from .. import _abi
 from ..merge import HeadMeanKeys
 
 
@@ -66,13 +64,9 @@ def _attention_forward(self, x, size: torch.Tensor = None):
         q, k, v = self.qkv(x).reshape(B, N, 3, self.num_heads, Cc // self.num_heads).permute(2, 0, 3, 1, 4)
     else:
         q = k = v = x.reshape(B, N, self.num_heads, Cc // self.num_heads).permute(0, 2, 1, 3)
-    bias = None
-    if size is not None:
-        bias = torch.zeros(B, 1, N, N, dtype=q.dtype, device=q.device)
-        bias[:, :, 1:, 1:] = _abi.log_of_size(size)[:, None, None, :, 0].to(q.dtype)
+    # the size bias sits on the non-class block of the logits only (timesformer.py:73-74): bias_skip
     drop_p = self.attn_drop.p if self.training else 0.0
-    out = F.scaled_dot_product_attention(q, k, v, attn_mask=bias, dropout_p=drop_p, scale=self.scale)
-    out = out.transpose(1, 2).reshape(B, N, Cc)
+    out = C.attention(q, k, v, size, self.scale, drop_p, bias_skip=True)
     if self.with_qkv:
         out = self.proj_drop(self.proj(out))
     return out, HeadMeanKeys(k[:, :, 1:, :])  # k.mean(1)[:, 1:, :] averaged inside the matching kernel

@@ -12,7 +12,6 @@ import torch
 import torch.nn.functional as F
 
 from . import _common as C
-from .. import _abi
 from ..merge import HeadMeanKeys
 
 
@@ -50,11 +49,9 @@ def _attention_forward(self, x, size: torch.Tensor = None, head_aggregation: str
         bias = torch.cat((self.q_bias, torch.zeros_like(self.v_bias, requires_grad=False), self.v_bias))
     qkv = F.linear(x, self.qkv.weight, bias).reshape(B, N, 3, self.num_heads, -1).permute(2, 0, 3, 1, 4)
     q, k, v = qkv[0], qkv[1], qkv[2]
-    # softmax(q*scale @ k^T + log(size)) @ v, by the framework's fused attention
-    attn_bias = None if size is None else _abi.log_of_size(size)[:, None, None, :, 0].to(q.dtype)
+    # softmax(q*scale @ k^T + log(size)) @ v: q, k, v are read in place from the qkv buffer
     drop_p = self.attn_drop.p if self.training else 0.0
-    out = F.scaled_dot_product_attention(q, k, v, attn_mask=attn_bias, dropout_p=drop_p, scale=self.scale)
-    out = self.proj_drop(self.proj(out.transpose(1, 2).reshape(B, N, -1)))
+    out = self.proj_drop(self.proj(C.attention(q, k, v, size, self.scale, drop_p)))
     if head_aggregation == "mean":
         metric = HeadMeanKeys(k)  # k.mean(1), averaged inside the matching kernel when the layer merges
     elif head_aggregation == "concat":

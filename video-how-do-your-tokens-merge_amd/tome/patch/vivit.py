@@ -60,20 +60,18 @@ def _self_attention_forward(self, hidden_states, size=None, head_aggregation="me
         return t.view(B, N, H, hd).permute(0, 2, 1, 3)
 
     q, k, v = heads(self.query(hidden_states)), heads(self.key(hidden_states)), heads(self.value(hidden_states))
-    bias = None if size is None else _abi.log_of_size(size)[:, None, None, :, 0].to(q.dtype)
     probs = None
     if output_attentions or head_mask is not None:
         scores = torch.matmul(q, k.transpose(-1, -2)) / math.sqrt(hd)
-        if bias is not None:
-            scores = scores + bias
+        if size is not None:
+            scores = scores + _abi.log_of_size(size)[:, None, None, :, 0].to(q.dtype)
         probs = self.dropout(F.softmax(scores, dim=-1))
         if head_mask is not None:
             probs = probs * head_mask
-        ctx = torch.matmul(probs, v)
+        ctx = torch.matmul(probs, v).permute(0, 2, 1, 3).reshape(B, N, H * hd)
     else:
         drop_p = self.dropout.p if self.training else 0.0
-        ctx = F.scaled_dot_product_attention(q, k, v, attn_mask=bias, dropout_p=drop_p)
-    ctx = ctx.permute(0, 2, 1, 3).reshape(B, N, H * hd)
+        ctx = C.attention(q, k, v, size, 1.0 / math.sqrt(hd), drop_p)
     if head_aggregation == "mean":
         metric = HeadMeanKeys(k)  # k.mean(1), averaged inside the matching kernel when the layer merges
     elif head_aggregation == "concat":
