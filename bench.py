@@ -36,6 +36,7 @@ import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md, chip-level parameters)
 MFMA_F32_PEAK_TFLOPS = 157.3  # v_mfma_f32_32x32x2_f32 dense peak (same table)
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak (same table); the patched attention runs on it
 
 EMBED, HEADS, HEAD_DIM, LAYERS = 768, 12, 64, 12
 DEFAULT_BATCH = 128  # clips per GPU per step: 64 -> 128 is +4.7 % clips/s (GEMM / attention efficiency), 96 -> +3 %
@@ -158,6 +159,32 @@ def measure_kernels(batch: int, t0: int, r: int, dev, reps: int = 10):
             stats["k_add_ln_rows"]["bytes"] += batch * (t - re) * EMBED * 2 * 4  # read x, a; write x', y
         x, size = x_out, s_out
     return stats
+
+
+def measure_attention(batch: int, t0: int, r: int, dev, reps: int = 5):
+    """The patched blocks' attention (tome_prop_attention, the caller on the near side of the merge path) over
+    the token counts of the 12 layers: device time per forward and TFLOP/s against the dense bf16 MFMA peak.
+    Reported next to the merge path, not as part of `roofline` (SURVEY.md 8d prices the merge path)."""
+    from tome import _abi
+    g = torch.Generator(device=dev).manual_seed(1)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ms = flops = 0.0
+    for t, _ in token_schedule(t0, r, LAYERS):
+        qkv = torch.randn(batch, t, 3, HEADS, HEAD_DIM, device=dev, generator=g).bfloat16()
+        q, k, v = qkv.permute(2, 0, 3, 1, 4)
+        for _ in range(2):
+            _abi.prop_attention(q, k, v, None, HEAD_DIM ** -0.5)
+        e0.record()
+        for _ in range(reps):
+            _abi.prop_attention(q, k, v, None, HEAD_DIM ** -0.5)
+        e1.record()
+        e1.synchronize()
+        ms += e0.elapsed_time(e1) / reps
+        flops += 4.0 * batch * HEADS * t * t * HEAD_DIM
+        del qkv, q, k, v
+    tf = flops / (ms / 1e3) / 1e12
+    return {"kernel": "k_prop_attention", "ms_per_step": round(ms, 3), "launches_per_step": LAYERS,
+            "TFLOP/s": round(tf, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "frac": round(tf / MFMA_BF16_PEAK_TFLOPS, 4)}
 
 
 def roofline_of(stats, batch: int):
@@ -324,6 +351,8 @@ def main():
                     "TFLOP/s": round(v["flops"] / (v["ms"] / 1e3) / 1e12, 2) if v["flops"] else None}
                 for k, v in stats.items()}
             out["merge_path_ms_per_step"] = round(sum(v["ms"] for v in stats.values()), 4)
+            with torch.no_grad():
+                out["attention_kernel"] = measure_attention(B, t0_tokens, args.r, dev)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.frames, args.r, args.cpu_clips, args.cpu_iters)
     if world > 1:

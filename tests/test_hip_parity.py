@@ -725,3 +725,97 @@ def test_more_than_2_31_elements():
         assert torch.equal(gx, fx[sl]) and torch.equal(gy, fy[sl]) and torch.equal(gs, fs[sl])
         bx, by = _abi.add_layernorm(x[sl].contiguous(), a[sl].contiguous(), w, b, 1e-6)
         assert torch.equal(bx, ax[sl]) and torch.equal(by, ay[sl])
+
+
+def _attn_reference(q, k, v, log_bias, scale, skip):
+    """fp32 softmax(q k^T * scale + bias) v -> [B, N, H*D]; the bias as the reference's patches build it."""
+    s = (q.float() @ k.float().transpose(-1, -2)) * scale
+    if log_bias is not None:
+        B, H, N, _ = q.shape
+        bias = torch.zeros(B, 1, N, N, device=q.device)
+        if skip:
+            bias[:, :, 1:, 1:] = log_bias[:, None, None, :]  # timesformer.py:73-74
+        else:
+            bias[:, :, :, :] = log_bias[:, None, None, :]  # videomae.py:62-63
+        s = s + bias
+    return (s.softmax(-1) @ v.float()).transpose(1, 2).reshape(q.shape[0], q.shape[2], -1)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.bfloat16, 1e-2), (torch.float16, 2e-3)])
+@pytest.mark.parametrize("B,H,N", [(1, 1, 64), (2, 3, 197), (1, 2, 100), (2, 12, 333), (1, 4, 1), (1, 2, 65),
+                                   (2, 5, 1568), (1, 2, 129)])
+def test_prop_attention_against_fp32_reference(B, H, N, dtype, tol):
+    """tome_prop_attention (ToMeAttention.forward, tome/patch/videomae.py:55-66 / timesformer.py:66-78 /
+    vivit.py:95-113) against an fp32 softmax(q k^T * scale + log(size)) v: plain, with the size bias on every key,
+    and in the TimeSformer form (class key / class query unbiased); q, k, v are strided views of one qkv buffer.
+    Tolerance: absolute, values are convex combinations of v ~ N(0,1); P is rounded to the 16-bit format before
+    the second product, as every fused attention does."""
+    from tome import _abi
+    g = torch.Generator(device=DEV).manual_seed(N * 7 + H)
+    qkv = torch.randn(B, N, 3, H, 64, device=DEV, generator=g).to(dtype)
+    q, k, v = qkv.permute(2, 0, 3, 1, 4)
+    for mode in ("none", "bias", "skip"):
+        n = N - (1 if mode == "skip" else 0)
+        size = log_b = None
+        if mode != "none":
+            if n <= 0:
+                continue
+            size = torch.randint(1, 30, (B, n, 1), device=DEV, generator=g).float()
+            log_b = size.log()[:, :, 0]
+        out = _abi.prop_attention(q, k, v, size, 0.125, bias_skip=(mode == "skip"))
+        want = _attn_reference(q, k, v, log_b, 0.125, mode == "skip")
+        assert out.shape == (B, N, H * 64) and out.dtype == dtype
+        assert float((out.float() - want).abs().max()) <= tol, mode
+
+
+def test_prop_attention_properties():
+    """Size-independent properties at full size (ViViT: 3137 tokens): (a) the weights of a query sum to one
+    (v = ones -> out = ones); (b) a key of size s counts like s copies of that key (what proportional attention
+    means); (c) a common factor on all sizes changes nothing; (d) separate q / k / v tensors (ViViT's three
+    projections) give the same result as views of one buffer."""
+    from tome import _abi
+    g = torch.Generator(device=DEV).manual_seed(3)
+    B, H, N = 2, 12, 3137
+    q = torch.randn(B, H, N, 64, device=DEV, generator=g).bfloat16()
+    k = torch.randn(B, H, N, 64, device=DEV, generator=g).bfloat16()
+    ones = torch.ones(B, H, N, 64, device=DEV).bfloat16()
+    size = torch.randint(1, 9, (B, N, 1), device=DEV, generator=g).float()
+    out = _abi.prop_attention(q, k, ones, size, 0.125)
+    assert float((out.float() - 1.0).abs().max()) <= 2 ** -7
+    # (b) small case: sizes as integer multiplicities
+    Bs, Hs, Ns = 1, 2, 40
+    qs = torch.randn(Bs, Hs, Ns, 64, device=DEV, generator=g).bfloat16()
+    ks = torch.randn(Bs, Hs, Ns, 64, device=DEV, generator=g).bfloat16()
+    vs = torch.randn(Bs, Hs, Ns, 64, device=DEV, generator=g).bfloat16()
+    mult = torch.randint(1, 4, (Ns,), device=DEV, generator=g)
+    rep = torch.repeat_interleave(torch.arange(Ns, device=DEV), mult)
+    a = _abi.prop_attention(qs, ks, vs, mult.float().reshape(1, Ns, 1), 0.125)
+    qpad = torch.zeros(Bs, Hs, rep.numel(), 64, device=DEV, dtype=torch.bfloat16)
+    qpad[:, :, :Ns] = qs
+    b_ = _abi.prop_attention(qpad, ks[:, :, rep].contiguous(), vs[:, :, rep].contiguous(), None, 0.125)[:, :Ns]
+    assert float((a.float() - b_.float()).abs().max()) <= 1e-2
+    # (c) scale invariance in the sizes
+    c1 = _abi.prop_attention(qs, ks, vs, mult.float().reshape(1, Ns, 1), 0.125)
+    c2 = _abi.prop_attention(qs, ks, vs, (mult.float() * 8.0).reshape(1, Ns, 1), 0.125)
+    assert float((c1.float() - c2.float()).abs().max()) <= 1e-2
+    # (d) views of a packed buffer vs separate tensors
+    qkv = torch.stack((qs, ks, vs)).permute(1, 3, 0, 2, 4).contiguous()  # [B, N, 3, H, 64]
+    qv, kv, vv = qkv.permute(2, 0, 3, 1, 4)
+    assert torch.equal(_abi.prop_attention(qv, kv, vv, None, 0.125), _abi.prop_attention(qs, ks, vs, None, 0.125))
+
+
+def test_prop_attention_refuses_what_it_cannot_do():
+    from tome import _abi
+    from tome._abi import TomeHipError
+    q = torch.randn(1, 2, 16, 64, device=DEV).bfloat16()
+    with pytest.raises(TomeHipError):
+        _abi.prop_attention(q.float(), q.float(), q.float(), None, 0.125)  # 16-bit only
+    with pytest.raises(TomeHipError):
+        _abi.prop_attention(q[..., :32], q[..., :32], q[..., :32], None, 0.125)  # head dim 64 only
+    with pytest.raises(TomeHipError):
+        _abi.prop_attention(q, q[:, :, :8], q, None, 0.125)  # shapes differ
+    with pytest.raises(TomeHipError):
+        _abi.prop_attention(q, q, q, torch.ones(1, 15, 1, device=DEV), 0.125)  # size length
+    with pytest.raises(TomeHipError):
+        _abi.prop_attention(q.cpu(), q.cpu(), q.cpu(), None, 0.125)  # no CPU path
+    assert not _abi.prop_attention_ok(q.float()) and _abi.prop_attention_ok(q)
