@@ -30,7 +30,6 @@
 #include "tome_common.h"
 
 #define ATT_D 64        // head dim
-#define ATT_BM 128      // queries per workgroup
 #define ATT_BN 64       // keys per tile
 #define ATT_KS 72       // K tile row stride in elements (144 B: conflict-free ds_read_b128 over 16 rows)
 #define ATT_VS 96       // V tile row stride in elements (192 B: conflict-free ds_read_b64_tr_b16 over 4 rows)
@@ -78,8 +77,9 @@ template <typename TX> __device__ __forceinline__ short att_bits(float f) {
     return s;
 }
 
-template <typename TX>
-__global__ __launch_bounds__(256) void k_prop_attention(AttnArgs a) {
+template <typename TX, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void k_prop_attention(AttnArgs a) {
+    constexpr int ATT_BM = 32 * WAVES;  // queries per workgroup
     __shared__ __attribute__((aligned(16))) short lds_k[ATT_BN * ATT_KS];
     __shared__ __attribute__((aligned(16))) short lds_v[ATT_BN * ATT_VS];
     __shared__ __attribute__((aligned(16))) float lds_bias[ATT_BN];  // log(size)*log2(e) per key, -inf out of range
@@ -120,14 +120,16 @@ __global__ __launch_bounds__(256) void k_prop_attention(AttnArgs a) {
 
     const int ntiles = (a.N + ATT_BN - 1) / ATT_BN;
     // staging: thread t moves chunks c = t and t + 256 (16 B each) of the 64 x 64 K and V tiles
-    const int r0 = tid >> 3, c0 = tid & 7;  // rows r0 and r0 + 32, 16-byte column c0
-    uint4 kreg[2], vreg[2];
+    constexpr int NST = 512 / (64 * WAVES);  // 16-byte chunks of each tile per thread (2 with 4 waves, 1 with 8)
+    constexpr int RSTEP = 8 * WAVES;         // rows covered by one pass of the workgroup
+    const int r0 = tid >> 3, c0 = tid & 7;   // rows r0 (+ RSTEP), 16-byte column c0
+    uint4 kreg[NST], vreg[NST];
     float breg = 0.0f, mreg = 0.0f;
     auto stage_load = [&](int t) {
         const int key0 = t * ATT_BN;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int key = key0 + r0 + 32 * i;
+        for (int i = 0; i < NST; ++i) {
+            const int key = key0 + r0 + RSTEP * i;
             if (key < a.N) {
                 kreg[i] = *reinterpret_cast<const uint4 *>(kp + (int64_t)key * a.k_sn + 8 * c0);
                 vreg[i] = *reinterpret_cast<const uint4 *>(vp + (int64_t)key * a.v_sn + 8 * c0);
@@ -147,9 +149,9 @@ __global__ __launch_bounds__(256) void k_prop_attention(AttnArgs a) {
     };
     auto stage_write = [&]() {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            *reinterpret_cast<uint4 *>(lds_k + (r0 + 32 * i) * ATT_KS + 8 * c0) = kreg[i];
-            *reinterpret_cast<uint4 *>(lds_v + (r0 + 32 * i) * ATT_VS + 8 * c0) = vreg[i];
+        for (int i = 0; i < NST; ++i) {
+            *reinterpret_cast<uint4 *>(lds_k + (r0 + RSTEP * i) * ATT_KS + 8 * c0) = kreg[i];
+            *reinterpret_cast<uint4 *>(lds_v + (r0 + RSTEP * i) * ATT_VS + 8 * c0) = vreg[i];
         }
         if (tid < ATT_BN) {
             lds_bias[tid] = breg;
@@ -212,7 +214,12 @@ __global__ __launch_bounds__(256) void k_prop_attention(AttnArgs a) {
         }
 #pragma unroll
         for (int v = 0; v < 16; ++v) mt = fmaxf(mt, fmaxf(s0[v], s1[v]));
-        mt = fmaxf(mt, __shfl_xor(mt, 32));
+        {   // the partner lane l^32 holds the other half of this query's keys: v_permlane32_swap exchanges the two
+            // halves in the vector ALU (no trip through the LDS pipeline in the middle of the softmax)
+            const unsigned mb = __float_as_uint(mt);
+            const auto sw = __builtin_amdgcn_permlane32_swap(mb, mb, false, false);
+            mt = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+        }
         const float m_new = fmaxf(m_run, mt);  // finite: every tile holds at least one key in range
         const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
         float lsum = 0.0f;

@@ -677,13 +677,25 @@ extern "C" int tome_prop_attention(const void *q, const void *k, const void *v, 
     a.o_sb = N * H * D; a.o_sn = H * D;
     a.log_size = log_size; a.ls_sb = log_size_stride;
     a.B = (int)B; a.H = (int)H; a.N = (int)N; a.scale = scale; a.bias_skip = bias_skip;
-    const int64_t qblocks = (N + ATT_BM - 1) / ATT_BM;
+    // queries per workgroup: 256 (eight waves share every staged K/V tile) unless the sequence is short
+    static const int waves_env = [] {
+        const char *e = getenv("TOME_ATTN_WAVES");
+        int v = e ? atoi(e) : 0;
+        return (v == 4 || v == 8) ? v : 0;
+    }();
+    const int waves = waves_env ? waves_env : (N > 128 ? 8 : 4);
+    const int64_t qblocks = (N + 32 * waves - 1) / (32 * waves);
     const int64_t bh8 = (B * H + 7) / 8 * 8;
     if (bh8 * qblocks > 0x7fffffffLL) return fail(TOME_EINVAL, "tome_prop_attention: grid too large");
     const dim3 grid((unsigned)(bh8 * qblocks));
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == TOME_BF16) hipLaunchKernelGGL(k_prop_attention<bf16_t>, grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(k_prop_attention<f16_t>, grid, dim3(256), 0, st, a);
+    if (dtype == TOME_BF16) {
+        if (waves == 8) hipLaunchKernelGGL((k_prop_attention<bf16_t, 8>), grid, dim3(512), 0, st, a);
+        else hipLaunchKernelGGL((k_prop_attention<bf16_t, 4>), grid, dim3(256), 0, st, a);
+    } else {
+        if (waves == 8) hipLaunchKernelGGL((k_prop_attention<f16_t, 8>), grid, dim3(512), 0, st, a);
+        else hipLaunchKernelGGL((k_prop_attention<f16_t, 4>), grid, dim3(256), 0, st, a);
+    }
     return check_launch("k_prop_attention");
 }
 
