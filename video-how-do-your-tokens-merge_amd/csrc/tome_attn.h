@@ -9,7 +9,8 @@
 // value per key added in the softmax, so proportional attention costs what plain attention costs.
 //
 // Structure (head dim 64, 16-bit q/k/v, fp32 softmax and accumulation):
-//   * workgroup = 4 waves = 128 queries of one (batch, head); wave w owns queries 32w .. 32w+31.
+//   * workgroup = 8 waves = 256 queries of one (batch, head) (4 waves for sequences up to 128); wave w owns
+//     queries 32w .. 32w+31.
 //   * keys/values stream through LDS in tiles of 64 keys (register-staged: the next tile's global loads are
 //     issued before the current tile's math and written to LDS behind it).
 //   * S^T = K Q^T on v_mfma_f32_32x32x16_bf16 (A = K rows from LDS, B = this wave's Q fragment in registers):
@@ -19,10 +20,12 @@
 //     row-major V tile through ds_read_b64_tr_b16 (4 consecutive keys of one channel per lane).
 //   * O^T accumulator: all 32 registers of a lane belong to its query -> the online-softmax rescale is a
 //     lane-local multiply.
-// Measured on MI355X (bf16): 480-570 TFLOP/s (8x12x3137: 500 us, 128x12x1472: 1.50 ms) against 415-500 for the
-// framework's kernel without a bias and 230-290 with one; per 64-key tile a wave issues ~195 VALU + 34
-// transcendental instructions next to 16 MFMAs, which is what bounds it (two instead of one barrier per tile,
-// two instead of four waves per SIMD, and a deferred rescale of O all measure within 1 %).
+// Measured on MI355X (bf16): 500-570 TFLOP/s (8x12x3137: 450-470 us, 64x12x1568: 850-900 us) against 415-500 for
+// the framework's kernel without a bias and 230-290 with one.  What was tried and makes no difference (within
+// 1-3 %): one instead of two barriers per tile (double-buffered LDS), two vs four waves per SIMD, a deferred
+// rescale of O, the scores of tile t+1 computed ahead of the softmax of tile t, sixteen waves per workgroup.
+// What does: eight waves (256 queries) per workgroup sharing each staged tile (+4-9 %) -- staging K/V through
+// registers into LDS costs 18 % of the time with four.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
