@@ -819,3 +819,47 @@ def test_prop_attention_refuses_what_it_cannot_do():
     with pytest.raises(TomeHipError):
         _abi.prop_attention(q.cpu(), q.cpu(), q.cpu(), None, 0.125)  # no CPU path
     assert not _abi.prop_attention_ok(q.float()) and _abi.prop_attention_ok(q)
+
+
+def _attn_fuzz_cases(count, seed):
+    import random
+    rng = random.Random(seed)
+    cases = []
+    for _ in range(count):
+        B, H = rng.randint(1, 3), rng.randint(1, 5)
+        N = rng.choice([1, 2, 31, 32, 33, 63, 64, 65, 127, 128, 129, 255, 256, 257]) if rng.random() < 0.6 else rng.randint(1, 700)
+        layout = rng.choice(["qkv", "separate", "padded"])
+        mode = rng.choice(["none", "bias", "skip"])
+        dtype = rng.choice(["bf16", "f16"])
+        cases.append((B, H, N, layout, mode, dtype))
+    return cases
+
+
+@pytest.mark.parametrize("case", _attn_fuzz_cases(60, 20261004), ids=lambda c: "B%dH%dN%d-%s-%s-%s" % c)
+def test_prop_attention_fuzz(case):
+    """Random shapes around the tile edges (32-query waves, 64-key tiles, 128/256-query workgroups), three memory
+    layouts of the heads (slices of one qkv buffer, three separate projections, rows with padding between the
+    heads) and the three bias forms, against the fp32 reference."""
+    from tome import _abi
+    B, H, N, layout, mode, dt = case
+    dtype = torch.bfloat16 if dt == "bf16" else torch.float16
+    g = torch.Generator(device=DEV).manual_seed(B * 1000003 + H * 1009 + N)
+    if layout == "qkv":
+        qkv = torch.randn(B, N, 3, H, 64, device=DEV, generator=g).to(dtype)
+        q, k, v = qkv.permute(2, 0, 3, 1, 4)
+    elif layout == "separate":
+        q, k, v = (torch.randn(B, N, H, 64, device=DEV, generator=g).to(dtype).permute(0, 2, 1, 3) for _ in range(3))
+    else:  # every token row carries 16 unused elements behind the heads
+        bufs = [torch.randn(B, N, H * 64 + 16, device=DEV, generator=g).to(dtype) for _ in range(3)]
+        q, k, v = (t[:, :, :H * 64].view(B, N, H, 64).permute(0, 2, 1, 3) for t in bufs)
+    n = N - (1 if mode == "skip" else 0)
+    size = log_b = None
+    if mode != "none" and n > 0:
+        size = torch.randint(1, 50, (B, n, 1), device=DEV, generator=g).float()
+        log_b = size.log()[:, :, 0]
+    elif mode == "skip":
+        mode = "none"
+    out = _abi.prop_attention(q, k, v, size, 0.125, bias_skip=(mode == "skip"))
+    want = _attn_reference(q, k, v, log_b, 0.125, mode == "skip")
+    tol = 1e-2 if dtype == torch.bfloat16 else 2e-3
+    assert float((out.float() - want).abs().max()) <= tol
