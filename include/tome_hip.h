@@ -39,7 +39,7 @@ enum tome_status {
     TOME_ELAUNCH = 3     /* HIP reported a launch error (text in tome_last_error()) */
 };
 
-#define TOME_ABI_VERSION 2
+#define TOME_ABI_VERSION 3
 
 int tome_abi_version(void);
 
@@ -175,16 +175,20 @@ int tome_drop_regrouped(const void *x, int dtype, int64_t B, int64_t F, int64_t 
  *     attn = softmax(q k^T * scale + size.log()[:, None, None, :, 0]) ; x = attn @ v
  *     (ToMeAttention.forward, tome/patch/videomae.py:55-66; vivit.py:95-113; timesformer.py:66-78 with the bias
  *      on the non-class block only: bias_skip = 1)
- * q, k, v: [B, H, N, 64] views of 16-bit tensors, element strides {batch, head, token} each (channels contiguous,
- * rows 16-byte aligned) -- e.g. the three slices of a [B, N, 3, H, 64] qkv buffer, read in place.
- * log_size: NULL (plain attention) or fp32 [B, N - bias_skip] with row stride log_size_stride: log of the token
- * sizes, added to the logits of key j (bias_skip = 1: key 0 and query 0 carry no bias, entry j-1 belongs to key j).
- * out: [B, N, H*64] contiguous, the layout the output projection reads.  fp32 softmax and accumulation.
+ * q: [B, H, N, 64], k, v: [B, H, Nk, 64] views of 16-bit tensors, element strides {batch, head, token} each (channels
+ * contiguous, rows 16-byte aligned) -- e.g. the three slices of a [B, N, 3, H, 64] qkv buffer, read in place.  Nk may
+ * differ from N (Motionformer's trajectory attention attends from every token to the keys of one frame at a time,
+ * tome/patch/motionformer.py:98-121).
+ * log_size: NULL (plain attention) or fp32 [B, Nk - bias_skip] with row stride log_size_stride: log of the token
+ * sizes, added to the logits of key j (bias_skip = 1, N == Nk: key 0 and query 0 carry no bias, entry j-1 belongs
+ * to key j).
+ * out: NULL strides -> [B, N, H*64] contiguous, the layout the output projection reads; else element strides
+ * {batch, head, token} of out[b, q, h, 0..63] (rows 8-byte aligned).  fp32 softmax and accumulation.
  */
 int tome_prop_attention(const void *q, const void *k, const void *v, int dtype, int64_t B, int64_t H, int64_t N,
-                        int64_t D, const int64_t *q_strides, const int64_t *k_strides, const int64_t *v_strides,
-                        const float *log_size, int64_t log_size_stride, int bias_skip, float scale, void *out,
-                        tome_stream_t stream);
+                        int64_t Nk, int64_t D, const int64_t *q_strides, const int64_t *k_strides,
+                        const int64_t *v_strides, const float *log_size, int64_t log_size_stride, int bias_skip,
+                        float scale, void *out, const int64_t *out_strides, tome_stream_t stream);
 
 /*
  * tome_add_layernorm  <-  the second residual of the patched block and the LayerNorm that consumes it:

@@ -304,6 +304,45 @@ def test_fused_block_equals_unfused_block_bf16(host_name, monkeypatch):
     assert float((o1 - o0).abs().max()) <= 0.05 * max(1.0, float(o0.abs().max()))
 
 
+@pytest.mark.parametrize("host_name", ["videomae", "vivit", "timesformer", "motionformer"])
+def test_attention_kernel_equals_framework_attention_bf16(host_name, monkeypatch):
+    """Proportional attention through tome_prop_attention (size bias per key inside the kernel; Motionformer: one
+    launch per frame of the trajectory attention's first stage) vs the framework's attention with the bias tensor
+    the reference builds: same token schedule, same first-layer matching, logits within bf16 noise."""
+    tome, H = _hosts()
+    from tome.patch import _common
+    torch.manual_seed(0)
+    if host_name == "videomae":
+        model = H["videomae"].VideoMAE(num_frames=8, img_size=64, patch_size=8, embed_dim=128, depth=3, num_heads=2,
+                                       num_classes=9)
+        patch, frames = tome.patch.videomae, 8
+    elif host_name == "vivit":
+        model = H["vivit"].ViViT(num_classes=9, image_size=64, num_frames=8, hidden_size=128, num_hidden_layers=3,
+                                 num_attention_heads=2, intermediate_size=256, tubelet_size=(2, 8, 8))
+        patch, frames = tome.patch.vivit, 8
+    elif host_name == "timesformer":
+        model = H["timesformer"].TimeSformer(num_frames=4, img_size=64, patch_size=8, embed_dim=128, depth=3,
+                                             num_heads=2, num_classes=9)
+        patch, frames = tome.patch.timesformer, 4
+    else:
+        model = H["motionformer"].Motionformer(img_size=64, patch_size=8, patch_size_temp=2, temporal_resolution=4,
+                                               embed_dim=128, depth=3, num_heads=2, num_classes=9)
+        patch, frames = tome.patch.motionformer, 8
+    model = model.to(DEV).to(torch.bfloat16).eval()
+    patch(model, prop_attn=True)
+    clip = torch.rand(3, 3, frames, 64, 64, device=DEV).to(torch.bfloat16)
+    outs = {}
+    for kernel in (True, False):
+        monkeypatch.setattr(_common, "_ATTN_KERNEL", kernel)
+        out, plans = _trace(tome, model, clip, 5)
+        outs[kernel] = (out.float(), plans, model._tome_info["size"].float().clone())
+    (o1, p1, s1), (o0, p0, s0) = outs[True], outs[False]
+    assert [s[1] for s, _ in p1] == [s[1] for s, _ in p0]
+    assert torch.equal(p1[0][1].src_idx, p0[0][1].src_idx) and torch.equal(p1[0][1].dst_idx, p0[0][1].dst_idx)
+    assert float(s1.sum()) == float(s0.sum())
+    assert float((o1 - o0).abs().max()) <= 0.05 * max(1.0, float(o0.abs().max()))
+
+
 _CFG_YAML = """\
 TRAIN:
   ENABLE: True

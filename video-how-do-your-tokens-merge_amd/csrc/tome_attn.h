@@ -47,10 +47,10 @@ struct AttnArgs {
     const void *q, *k, *v;
     void *out;
     int64_t q_sb, q_sh, q_sn, k_sb, k_sh, k_sn, v_sb, v_sh, v_sn;  // element strides: batch, head, token
-    int64_t o_sb, o_sn;                                            // out [B, N, H*64]
-    const float *log_size;                                         // NULL or [B, N - bias_skip] fp32
+    int64_t o_sb, o_sh, o_sn;                                      // out element strides (contiguous: [B, Nq, H*64])
+    const float *log_size;                                         // NULL or [B, Nk - bias_skip] fp32
     int64_t ls_sb;
-    int B, H, N;
+    int B, H, N, Nk;                                               // N queries, Nk keys per (batch, head)
     float scale;
     int bias_skip;  // 1: TimeSformer form -- key 0 and query 0 carry no bias, log_size[j-1] belongs to key j
 };
@@ -121,7 +121,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_prop_attention(AttnArgs a) {
     for (int v = 0; v < 16; ++v) o0[v] = o1[v] = 0.0f;
     float m_run = -INFINITY, l_run = 0.0f;
 
-    const int ntiles = (a.N + ATT_BN - 1) / ATT_BN;
+    const int ntiles = (a.Nk + ATT_BN - 1) / ATT_BN;
     // staging: thread t moves chunks c = t and t + 256 (16 B each) of the 64 x 64 K and V tiles
     constexpr int NST = 512 / (64 * WAVES);  // 16-byte chunks of each tile per thread (2 with 4 waves, 1 with 8)
     constexpr int RSTEP = 8 * WAVES;         // rows covered by one pass of the workgroup
@@ -133,7 +133,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_prop_attention(AttnArgs a) {
 #pragma unroll
         for (int i = 0; i < NST; ++i) {
             const int key = key0 + r0 + RSTEP * i;
-            if (key < a.N) {
+            if (key < a.Nk) {
                 kreg[i] = *reinterpret_cast<const uint4 *>(kp + (int64_t)key * a.k_sn + 8 * c0);
                 vreg[i] = *reinterpret_cast<const uint4 *>(vp + (int64_t)key * a.v_sn + 8 * c0);
             } else {
@@ -143,7 +143,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_prop_attention(AttnArgs a) {
         }
         if (tid < ATT_BN) {
             const int key = key0 + tid;
-            const bool in = key < a.N;
+            const bool in = key < a.Nk;
             float bv = 0.0f;
             if (in && lsp && key >= a.bias_skip) bv = lsp[key - a.bias_skip] * LOG2E;
             breg = in ? bv : -INFINITY;
@@ -267,7 +267,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_prop_attention(AttnArgs a) {
     const float l_tot = l_run + __shfl_xor(l_run, 32);
     const float inv = 1.0f / l_tot;
     if (qrow < a.N) {
-        short *op = reinterpret_cast<short *>(a.out) + b * a.o_sb + (int64_t)qrow * a.o_sn + h * ATT_D;
+        short *op = reinterpret_cast<short *>(a.out) + b * a.o_sb + (int64_t)qrow * a.o_sn + h * a.o_sh;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             att_s16x4 w0, w1;

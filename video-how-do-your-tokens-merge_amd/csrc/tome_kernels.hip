@@ -653,30 +653,38 @@ extern "C" int tome_drop_regrouped(const void *x, int dtype, int64_t B, int64_t 
 }
 
 extern "C" int tome_prop_attention(const void *q, const void *k, const void *v, int dtype, int64_t B, int64_t H,
-                                   int64_t N, int64_t D, const int64_t *q_strides, const int64_t *k_strides,
-                                   const int64_t *v_strides, const float *log_size, int64_t log_size_stride,
-                                   int bias_skip, float scale, void *out, tome_stream_t stream) {
-    if (!q || !k || !v || !out || !q_strides || !k_strides || !v_strides || B <= 0 || H <= 0 || N <= 0)
+                                   int64_t N, int64_t Nk, int64_t D, const int64_t *q_strides,
+                                   const int64_t *k_strides, const int64_t *v_strides, const float *log_size,
+                                   int64_t log_size_stride, int bias_skip, float scale, void *out,
+                                   const int64_t *out_strides, tome_stream_t stream) {
+    if (!q || !k || !v || !out || !q_strides || !k_strides || !v_strides || B <= 0 || H <= 0 || N <= 0 || Nk <= 0)
         return fail(TOME_EINVAL, "tome_prop_attention: bad shape/pointer");
     if (D != ATT_D) return fail(TOME_EINVAL, "tome_prop_attention: head dim %lld (only 64)", (long long)D);
     if (dtype != TOME_BF16 && dtype != TOME_F16) return fail(TOME_EINVAL, "tome_prop_attention: 16-bit q/k/v only");
     if (bias_skip != 0 && bias_skip != 1) return fail(TOME_EINVAL, "tome_prop_attention: bias_skip %d", bias_skip);
-    if (B * H > 0x7fffffffLL / 64 || N > 0x7fffffffLL / 4) return fail(TOME_EINVAL, "tome_prop_attention: too large");
+    if (bias_skip && N != Nk) return fail(TOME_EINVAL, "tome_prop_attention: bias_skip needs as many keys as queries");
+    if (B * H > 0x7fffffffLL / 64 || N > 0x7fffffffLL / 4 || Nk > 0x7fffffffLL / 4)
+        return fail(TOME_EINVAL, "tome_prop_attention: too large");
     const int64_t *ss[3] = {q_strides, k_strides, v_strides};
     const void *pp[3] = {q, k, v};
     for (int i = 0; i < 3; ++i) {
         if (!aligned16(pp[i]) || ss[i][0] % 8 || ss[i][1] % 8 || ss[i][2] % 8 || ss[i][2] < D)
             return fail(TOME_EINVAL, "tome_prop_attention: q/k/v rows must be 16-byte aligned (strides %% 8 == 0)");
     }
-    if (!aligned16(out)) return fail(TOME_EINVAL, "tome_prop_attention: out not 16-byte aligned");
     AttnArgs a;
     a.q = q; a.k = k; a.v = v; a.out = out;
     a.q_sb = q_strides[0]; a.q_sh = q_strides[1]; a.q_sn = q_strides[2];
     a.k_sb = k_strides[0]; a.k_sh = k_strides[1]; a.k_sn = k_strides[2];
     a.v_sb = v_strides[0]; a.v_sh = v_strides[1]; a.v_sn = v_strides[2];
-    a.o_sb = N * H * D; a.o_sn = H * D;
+    if (out_strides) {  // {batch, head, token} element strides of out[b, q, h, 0..63]; rows 8-byte aligned
+        if (out_strides[0] % 4 || out_strides[1] % 4 || out_strides[2] % 4 || ((uintptr_t)out & 7))
+            return fail(TOME_EINVAL, "tome_prop_attention: out rows must be 8-byte aligned");
+        a.o_sb = out_strides[0]; a.o_sh = out_strides[1]; a.o_sn = out_strides[2];
+    } else {
+        a.o_sb = N * H * D; a.o_sh = D; a.o_sn = H * D;
+    }
     a.log_size = log_size; a.ls_sb = log_size_stride;
-    a.B = (int)B; a.H = (int)H; a.N = (int)N; a.scale = scale; a.bias_skip = bias_skip;
+    a.B = (int)B; a.H = (int)H; a.N = (int)N; a.Nk = (int)Nk; a.scale = scale; a.bias_skip = bias_skip;
     // queries per workgroup: 256 (eight waves share every staged K/V tile) unless the sequence is short
     static const int waves_env = [] {
         const char *e = getenv("TOME_ATTN_WAVES");

@@ -24,7 +24,7 @@ SYMBOLS = (
     "tome_profile_enable", "tome_profile_read",
 )
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 DTYPES = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}
 MODES = {"sum": 0, "mean": 1, "amax": 2, "max": 2, "prod": 3, "amin": 4, "min": 4}
 
@@ -80,7 +80,8 @@ def lib() -> ctypes.CDLL:
     L.tome_merge.restype = i32
     L.tome_merge.argtypes = [vp, i32, i64, i64, i64, i64, vp, vp, vp, i32, i32, vp, vp, vp]
     L.tome_prop_attention.restype = i32
-    L.tome_prop_attention.argtypes = [vp, vp, vp, i32, i64, i64, i64, i64, vp, vp, vp, vp, i64, i32, ctypes.c_float, vp, vp]
+    L.tome_prop_attention.argtypes = [vp, vp, vp, i32, i64, i64, i64, i64, i64, vp, vp, vp, vp, i64, i32, ctypes.c_float,
+                                      vp, vp, vp]
     L.tome_drop_regrouped.restype = i32
     L.tome_drop_regrouped.argtypes = [vp, i32, i64, i64, i64, i64, i64, i32, vp, vp, vp]
     L.tome_drop.restype = i32
@@ -496,32 +497,52 @@ def prop_attention_ok(q: torch.Tensor) -> bool:
 
 
 def prop_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, size: Optional[torch.Tensor], scale: float,
-                   bias_skip: bool = False) -> torch.Tensor:
-    """softmax(q k^T * scale + log(size) on the keys) v for [B, H, N, 64] head views (any strides with contiguous
-    channels: the slices of a qkv buffer are read in place); returns [B, N, H*64].  `size` is the token size
-    tensor [B, N(-1), 1] (its log comes from the merge kernel when that emitted it) or None.  bias_skip: the
-    TimeSformer form -- key 0 / query 0 unbiased, size describes keys 1..N-1."""
+                   bias_skip: bool = False, log_bias: Optional[torch.Tensor] = None,
+                   out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """softmax(q k^T * scale + log(size) on the keys) v for head views q [B, H, N, 64], k / v [B, H, Nk, 64] (any
+    strides with contiguous channels: the slices of a qkv buffer are read in place); returns [B, N, H*64].
+    `size` is the token size tensor [B, Nk(-1), 1] (its log comes from the merge kernel when that emitted it),
+    or `log_bias` an fp32 [B, Nk(-1)] view that already holds the bias, or both None.  bias_skip: the TimeSformer
+    form -- key 0 / query 0 unbiased, the bias describes keys 1..N-1.  `out`: a [B, N, H, 64] view (channels
+    contiguous) to write into instead of a fresh tensor."""
     for t, name in ((q, "q"), (k, "k"), (v, "v")):
         require_device(t, f"prop_attention({name})")
-        if not prop_attention_ok(t) or t.shape != q.shape or t.dtype != q.dtype or t.device != q.device:
+        if not prop_attention_ok(t) or t.dtype != q.dtype or t.device != q.device:
             raise TomeHipError(f"prop_attention: {name} must be a [B, H, N, 64] 16-bit view with 16-byte aligned rows, "
                                f"got {tuple(t.shape)} {t.dtype} strides {t.stride()}")
     B, H, N, D = q.shape
+    if k.shape != v.shape or k.shape[:2] != (B, H):
+        raise TomeHipError(f"prop_attention: q {tuple(q.shape)}, k {tuple(k.shape)}, v {tuple(v.shape)} do not match")
+    Nk = k.shape[2]
+    if bias_skip and Nk != N:
+        raise TomeHipError("prop_attention: bias_skip needs as many keys as queries")
+    nb = Nk - (1 if bias_skip else 0)
     log = None
     if size is not None:
-        want = (B, N - (1 if bias_skip else 0), 1)
-        if tuple(size.shape) != want:
-            raise TomeHipError(f"prop_attention: size must be {want}, got {tuple(size.shape)}")
+        if tuple(size.shape) != (B, nb, 1):
+            raise TomeHipError(f"prop_attention: size must be {(B, nb, 1)}, got {tuple(size.shape)}")
         log = log_of_size(size).reshape(B, -1).float().contiguous()
-    out = torch.empty((B, N, H * D), dtype=q.dtype, device=q.device)
+    elif log_bias is not None:
+        if tuple(log_bias.shape) != (B, nb) or log_bias.dtype != torch.float32 or log_bias.stride(1) != 1 \
+                or log_bias.device != q.device:
+            raise TomeHipError(f"prop_attention: log_bias must be an fp32 {(B, nb)} view with contiguous rows")
+        log = log_bias
+    ostr = None
+    if out is None:
+        result = out = torch.empty((B, N, H * D), dtype=q.dtype, device=q.device)
+    else:
+        if tuple(out.shape) != (B, N, H, D) or out.dtype != q.dtype or out.device != q.device or out.stride(3) != 1:
+            raise TomeHipError(f"prop_attention: out must be a {(B, N, H, D)} view of the q dtype with contiguous channels")
+        ostr = (ctypes.c_int64 * 3)(out.stride(0), out.stride(2), out.stride(1))
+        result = out
     strides = [(ctypes.c_int64 * 3)(*t.stride()[:3]) for t in (q, k, v)]
     with _on_device(q.device):
-        rc = lib().tome_prop_attention(q.data_ptr(), k.data_ptr(), v.data_ptr(), dtype_code(q, "q"), B, H, N, D,
+        rc = lib().tome_prop_attention(q.data_ptr(), k.data_ptr(), v.data_ptr(), dtype_code(q, "q"), B, H, N, Nk, D,
                                        strides[0], strides[1], strides[2], _ptr(log),
                                        0 if log is None else log.stride(0), 1 if bias_skip else 0, float(scale),
-                                       out.data_ptr(), _stream(q.device))
+                                       out.data_ptr(), ostr, _stream(q.device))
     _check(rc, "tome_prop_attention")
-    return out
+    return result
 
 
 def drop_regrouped(plan: MatchPlan, x_full: torch.Tensor, frames: int, has_cls: bool = True) -> torch.Tensor:

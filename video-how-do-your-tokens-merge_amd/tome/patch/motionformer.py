@@ -40,20 +40,39 @@ def _trajectory_forward(self, x, seq_len=196, num_frames=8, approx="none", num_l
     F = num_frames
     P = (N - 1) // F
     h = self.num_heads
-    q, k, v = self.qkv(x).chunk(3, dim=-1)
-    q, k, v = (rearrange(t, "b n (h d) -> (b h) n d", h=h) for t in (q, k, v))
+    qkv = self.qkv(x)
+    hd = qkv.shape[-1] // (3 * h)
+    heads = qkv.view(B, N, 3, h, hd).permute(2, 0, 3, 1, 4)  # q, k, v as [B, h, N, hd] views of the projection
+    fused = (C._ATTN_KERNEL and not (self.training and self.attn_drop.p > 0.0) and all(_abi.prop_attention_ok(t) for t in heads))
+    q, k, v = (rearrange(t, "b n (h d) -> (b h) n d", h=h) for t in qkv.chunk(3, dim=-1))
     (cls_q, q_), (cls_k, k_), (cls_v, v_) = ((t[:, 0:1], t[:, 1:]) for t in (q, k, v))
     cls_out = rearrange(qkv_attn(cls_q * self.scale, k, v), "(b h) f d -> b f (h d)", f=1, h=h)
-    q_dot_k = rearrange(q_ @ k_.transpose(-2, -1), "b q (f n) -> b q f n", f=F) * self.scale
+    # flat per-key bias in the reference's '(s f)' order (motionformer.py:107-111): key j of the (f n)-ordered
+    # sequence gets log(size) of (s = j // F, f = j % F)
+    log_flat = None
     if size is not None:
-        q_dot_k = rearrange(q_dot_k, "(b h) q f n -> b h q (f n)", h=h, f=F)
-        log_seq = rearrange(_abi.log_of_size(size), "(b f) s i -> b (s f) i", f=F)  # log commutes with the regroup
-        q_dot_k = q_dot_k + log_seq[:, None, None, :, 0].to(q_dot_k.dtype)
-        q_dot_k = rearrange(q_dot_k, "b h q (f n) -> (b h) q f n", h=h, f=F)
-    attn = self.attn_drop(q_dot_k.softmax(dim=-1))
-    v_ = rearrange(v_, "b (f n) d -> b f n d", f=F, n=P)
-    y = torch.einsum("b q f n, b f n d -> b q f d", attn, v_)
-    y = rearrange(y, "(b h) s f d -> b s f (h d)", b=B)
+        log_flat = rearrange(_abi.log_of_size(size), "(b f) s i -> b (s f) i", f=F)[:, :, 0]
+    if fused:
+        # every token attends to the P keys of ONE frame at a time (softmax per frame): F launches of the attention
+        # kernel, queries and keys read in place from the qkv buffer, each writing its slice of y '(b) s f (h d)';
+        # the [B*h, N, N] logits, their softmax and the attn @ v product never exist
+        y = torch.empty((B, N - 1, F, h * hd), dtype=x.dtype, device=x.device)
+        lf = None if log_flat is None else log_flat.float().contiguous()
+        for f in range(F):
+            sl = slice(1 + f * P, 1 + (f + 1) * P)
+            _abi.prop_attention(heads[0][:, :, 1:], heads[1][:, :, sl], heads[2][:, :, sl], None, self.scale,
+                                log_bias=None if lf is None else lf[:, f * P:(f + 1) * P],
+                                out=y[:, :, f].view(B, N - 1, h, hd))
+    else:
+        q_dot_k = rearrange(q_ @ k_.transpose(-2, -1), "b q (f n) -> b q f n", f=F) * self.scale
+        if log_flat is not None:
+            q_dot_k = rearrange(q_dot_k, "(b h) q f n -> b h q (f n)", h=h, f=F)
+            q_dot_k = q_dot_k + log_flat[:, None, None, :].to(q_dot_k.dtype)
+            q_dot_k = rearrange(q_dot_k, "b h q (f n) -> (b h) q f n", h=h, f=F)
+        attn = self.attn_drop(q_dot_k.softmax(dim=-1))
+        v_ = rearrange(v_, "b (f n) d -> b f n d", f=F, n=P)
+        y = torch.einsum("b q f n, b f n d -> b q f d", attn, v_)
+        y = rearrange(y, "(b h) s f d -> b s f (h d)", b=B)
     y_diag = rearrange(y, "b (g n) f d -> b g n f d", g=F)
     y_diag = torch.diagonal(y_diag, dim1=-4, dim2=-2)
     y_diag = rearrange(y_diag, "b n d f -> b (f n) d", f=F)
