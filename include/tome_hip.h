@@ -191,6 +191,17 @@ int tome_prop_attention(const void *q, const void *k, const void *v, int dtype, 
                         float scale, void *out, const int64_t *out_strides, tome_stream_t stream);
 
 /*
+ * tome_trajectory_mix  <-  the temporal stage of ToMeTrajectoryAttention.forward (tome/patch/motionformer.py:122-139):
+ *     attn = softmax(einsum('b h s d, b h s f d -> b h s f', q2 * scale, k2)); x = einsum('b h s f, b h s f d -> b h s d', attn, v2)
+ * q2 [B, S, H*64]; k2, val [B, S, F, H*64] views whose (b, s, f) rows are k_row_stride / v_row_stride elements apart
+ * (k2 = first half of the proj_kv output, val = the trajectory tokens or its second half); out [B, S, H*64];
+ * tattn NULL or fp32 [B, H, S, F].  16-bit tensors, head dim 64, H <= 16, F <= 8; fp32 arithmetic inside.
+ */
+int tome_trajectory_mix(const void *q2, const void *k2, const void *val, int dtype, int64_t B, int64_t S, int64_t F,
+                        int64_t H, int64_t D, int64_t k_row_stride, int64_t v_row_stride, float scale, void *out,
+                        float *tattn, tome_stream_t stream);
+
+/*
  * tome_add_layernorm  <-  the second residual of the patched block and the LayerNorm that consumes it:
  *     x = x + self.drop_path(self.mlp(self.norm2(x)))      (tome/patch/videomae.py:29)
  *     ... next ToMeBlock.forward: self.norm1(x)            (tome/patch/videomae.py:19)

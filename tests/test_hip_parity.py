@@ -863,3 +863,29 @@ def test_prop_attention_fuzz(case):
     want = _attn_reference(q, k, v, log_b, 0.125, mode == "skip")
     tol = 1e-2 if dtype == torch.bfloat16 else 2e-3
     assert float((out.float() - want).abs().max()) <= tol
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.bfloat16, 2e-2), (torch.float16, 3e-3)])
+@pytest.mark.parametrize("B,S,F,H", [(2, 37, 8, 12), (1, 5, 4, 2), (3, 196, 8, 16), (1, 1, 1, 1), (2, 64, 3, 5)])
+def test_trajectory_mix_against_fp32_reference(B, S, F, H, dtype, tol):
+    """tome_trajectory_mix (temporal stage of ToMeTrajectoryAttention.forward, tome/patch/motionformer.py:122-139)
+    against the fp32 einsum / softmax / einsum of the reference, with k2 and val as strided halves of one
+    proj_kv buffer (as in the model) and as separate tensors."""
+    from tome import _abi
+    g = torch.Generator(device=DEV).manual_seed(B * 100 + S + F + H)
+    C = H * 64
+    q2 = torch.randn(B, S, C, device=DEV, generator=g).to(dtype)
+    kv = torch.randn(B, S, F, 2 * C, device=DEV, generator=g).to(dtype)
+    y = torch.randn(B, S, F, C, device=DEV, generator=g).to(dtype)
+    scale = 0.125
+    for k2, val in ((kv[..., :C], kv[..., C:]), (kv[..., :C], y)):
+        out, attn = _abi.trajectory_mix(q2, k2, val, H, scale)
+        qh = q2.float().view(B, S, H, 64).permute(0, 2, 1, 3) * scale
+        kh = k2.float().reshape(B, S, F, H, 64).permute(0, 3, 1, 2, 4)
+        vh = val.float().reshape(B, S, F, H, 64).permute(0, 3, 1, 2, 4)
+        want_attn = torch.einsum("b h s d, b h s f d -> b h s f", qh, kh).softmax(dim=-1)
+        want = torch.einsum("b h s f, b h s f d -> b h s d", want_attn, vh).permute(0, 2, 1, 3).reshape(B, S, C)
+        assert out.shape == (B, S, C) and out.dtype == dtype and attn.shape == (B, H, S, F)
+        assert float((attn - want_attn).abs().max()) <= 1e-4
+        assert float((out.float() - want).abs().max()) <= tol
+    assert not _abi.trajectory_mix_ok(q2.float(), kv[..., :C].float(), y.float(), H)

@@ -281,3 +281,94 @@ __global__ __launch_bounds__(64 * WAVES) void k_prop_attention(AttnArgs a) {
         }
     }
 }
+
+// ------------------------------------------------------------------------------------------------
+// k_trajectory_mix: the temporal stage of Motionformer's trajectory attention as one streaming pass
+// (ToMeTrajectoryAttention.forward, tome/patch/motionformer.py:122-139):
+//     tattn = softmax_f( (q2 * scale) . k2[f] )          one logit per frame of the token's trajectory
+//     out   = sum_f tattn[f] * val[f]
+// per (batch, token, head).  q2 [B, S, H*64]; k2 and val [B, S, F, H*64] views with a row stride each (k2 is the
+// first half of the proj_kv output, val the trajectory tokens y or the second half); out [B, S, H*64];
+// tattn [B, H, S, F] fp32 (optional).  One wave per token: lane l owns the 16-byte chunks l and l + 64 of the
+// H*64 channels (H <= 16), the 8 lanes of a head reduce their partial dot products by xor-shuffles, the F <= 16
+// weights of a head live in registers, everything is loaded before it is used.  HBM bound: k2 and val are each
+// read once -- the five element-wise / reduction passes it replaces moved them three times.
+// ------------------------------------------------------------------------------------------------
+#define TRAJ_MAXF 8
+
+template <typename TX>
+__global__ __launch_bounds__(256) void k_trajectory_mix(const TX *__restrict__ q2, const TX *__restrict__ k2,
+                                                        const TX *__restrict__ val, int64_t rows, int S, int F, int H,
+                                                        int64_t k_row, int64_t v_row, float scale,
+                                                        TX *__restrict__ out, float *__restrict__ tattn) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (row >= rows) return;  // wave-uniform
+    const int C = H * 64, chunks = C >> 3;
+    const TX *qr = q2 + row * C;
+    const TX *kr = k2 + row * F * k_row;
+    const TX *vr = val + row * F * v_row;
+    float acc[2][8];
+    float w[2][TRAJ_MAXF];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int c = lane + 64 * i;
+        const bool on = c < chunks;
+        float qv[8];
+        if (on) load_pack<TX, 8>(qr + 8 * c, qv);
+        uint4 kraw[TRAJ_MAXF];
+#pragma unroll
+        for (int f = 0; f < TRAJ_MAXF; ++f)
+            if (on && f < F) kraw[f] = *reinterpret_cast<const uint4 *>(kr + (int64_t)f * k_row + 8 * c);
+        float lg[TRAJ_MAXF];
+#pragma unroll
+        for (int f = 0; f < TRAJ_MAXF; ++f) {
+            float d = 0.0f;
+            if (on && f < F) {
+                Pack<TX, 8> pk;
+                __builtin_memcpy(&pk, &kraw[f], 16);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) d = __builtin_fmaf(qv[e], to_f32(pk.e[e]), d);
+            }
+            // the 8 lanes of a head (consecutive chunks) hold its 64 channels
+            d += __shfl_xor(d, 1);
+            d += __shfl_xor(d, 2);
+            d += __shfl_xor(d, 4);
+            lg[f] = (f < F) ? d * scale : -INFINITY;
+        }
+        float m = lg[0];
+#pragma unroll
+        for (int f = 1; f < TRAJ_MAXF; ++f) m = fmaxf(m, lg[f]);
+        float sum = 0.0f;
+#pragma unroll
+        for (int f = 0; f < TRAJ_MAXF; ++f) {
+            w[i][f] = (f < F) ? __expf(lg[f] - m) : 0.0f;
+            sum += w[i][f];
+        }
+        const float inv = 1.0f / sum;
+#pragma unroll
+        for (int f = 0; f < TRAJ_MAXF; ++f) w[i][f] *= inv;
+        if (tattn && on && (c & 7) == 0) {
+            const int h = c >> 3;
+            const int64_t b = row / S, s = row - b * S;
+            float *tp = tattn + ((b * H + h) * S + s) * F;
+            for (int f = 0; f < F; ++f) tp[f] = w[i][f];
+        }
+        uint4 vraw[TRAJ_MAXF];
+#pragma unroll
+        for (int f = 0; f < TRAJ_MAXF; ++f)
+            if (on && f < F) vraw[f] = *reinterpret_cast<const uint4 *>(vr + (int64_t)f * v_row + 8 * c);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[i][e] = 0.0f;
+#pragma unroll
+        for (int f = 0; f < TRAJ_MAXF; ++f) {
+            if (on && f < F) {
+                Pack<TX, 8> pk;
+                __builtin_memcpy(&pk, &vraw[f], 16);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[i][e] = __builtin_fmaf(w[i][f], to_f32(pk.e[e]), acc[i][e]);
+            }
+        }
+        if (on) store_pack<TX, 8>(out + row * C + 8 * c, acc[i]);
+    }
+}

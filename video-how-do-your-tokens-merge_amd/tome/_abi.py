@@ -18,7 +18,8 @@ SYMBOLS = (
     "tome_abi_version", "tome_last_error", "tome_effective_r", "tome_match_workspace_bytes", "tome_match",
     "tome_match_keys",
     "tome_match_scores", "tome_edge_keep", "tome_merge_wavg", "tome_merge_wavg_ln", "tome_merge_wavg_regrouped",
-    "tome_merge_wavg_regrouped_ln", "tome_add_layernorm", "tome_prop_attention", "tome_merge", "tome_drop",
+    "tome_merge_wavg_regrouped_ln", "tome_add_layernorm", "tome_prop_attention", "tome_trajectory_mix", "tome_merge",
+    "tome_drop",
     "tome_drop_regrouped",
     "tome_unmerge",
     "tome_profile_enable", "tome_profile_read",
@@ -82,6 +83,8 @@ def lib() -> ctypes.CDLL:
     L.tome_prop_attention.restype = i32
     L.tome_prop_attention.argtypes = [vp, vp, vp, i32, i64, i64, i64, i64, i64, vp, vp, vp, vp, i64, i32, ctypes.c_float,
                                       vp, vp, vp]
+    L.tome_trajectory_mix.restype = i32
+    L.tome_trajectory_mix.argtypes = [vp, vp, vp, i32, i64, i64, i64, i64, i64, i64, i64, ctypes.c_float, vp, vp, vp]
     L.tome_drop_regrouped.restype = i32
     L.tome_drop_regrouped.argtypes = [vp, i32, i64, i64, i64, i64, i64, i32, vp, vp, vp]
     L.tome_drop.restype = i32
@@ -543,6 +546,39 @@ def prop_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, size: Opti
                                        out.data_ptr(), ostr, _stream(q.device))
     _check(rc, "tome_prop_attention")
     return result
+
+
+def trajectory_mix_ok(q2: torch.Tensor, k2: torch.Tensor, val: torch.Tensor, heads: int) -> bool:
+    """Can tome_trajectory_mix take these?  q2 [B, S, C], k2 / val [B, S, F, C] views (rows contiguous over C,
+    (b, s, f) rows evenly spaced), 16-bit, head dim 64, at most 16 heads and 8 frames."""
+    if not (q2.is_cuda and q2.dtype in (torch.bfloat16, torch.float16) and q2.dim() == 3 and k2.dim() == 4):
+        return False
+    B, S, C = q2.shape
+    F = k2.shape[2]
+    def rows_ok(t):
+        return (t.shape == (B, S, F, C) and t.dtype == q2.dtype and t.stride(3) == 1 and t.stride(2) % 8 == 0
+                and t.stride(1) == F * t.stride(2) and t.stride(0) == S * t.stride(1) and t.data_ptr() % 16 == 0)
+    return (C == heads * 64 and heads <= 16 and F <= 8 and q2.is_contiguous() and q2.data_ptr() % 16 == 0
+            and rows_ok(k2) and rows_ok(val) and not (torch.is_grad_enabled() and (q2.requires_grad or k2.requires_grad)))
+
+
+def trajectory_mix(q2: torch.Tensor, k2: torch.Tensor, val: torch.Tensor, heads: int, scale: float,
+                   want_attn: bool = True):
+    """softmax over the F frames of (q2*scale . k2[f]) per (batch, token, head), then the weighted sum of val[f]:
+    returns (out [B, S, C], attn [B, heads, S, F] fp32 or None)."""
+    if not trajectory_mix_ok(q2, k2, val, heads):
+        raise TomeHipError("trajectory_mix: unsupported tensors (16-bit, head dim 64, <= 16 heads, <= 8 frames, "
+                           "evenly spaced 16-byte aligned rows)")
+    B, S, C = q2.shape
+    F = k2.shape[2]
+    out = torch.empty((B, S, C), dtype=q2.dtype, device=q2.device)
+    attn = torch.empty((B, heads, S, F), dtype=torch.float32, device=q2.device) if want_attn else None
+    with _on_device(q2.device):
+        rc = lib().tome_trajectory_mix(q2.data_ptr(), k2.data_ptr(), val.data_ptr(), dtype_code(q2, "q2"), B, S, F, heads,
+                                       64, k2.stride(2), val.stride(2), float(scale), out.data_ptr(), _ptr(attn),
+                                       _stream(q2.device))
+    _check(rc, "tome_trajectory_mix")
+    return out, attn
 
 
 def drop_regrouped(plan: MatchPlan, x_full: torch.Tensor, frames: int, has_cls: bool = True) -> torch.Tensor:

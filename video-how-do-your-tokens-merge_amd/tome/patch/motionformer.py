@@ -76,14 +76,23 @@ def _trajectory_forward(self, x, seq_len=196, num_frames=8, approx="none", num_l
     y_diag = rearrange(y, "b (g n) f d -> b g n f d", g=F)
     y_diag = torch.diagonal(y_diag, dim1=-4, dim2=-2)
     y_diag = rearrange(y_diag, "b n d f -> b (f n) d", f=F)
-    q2 = rearrange(self.proj_q(y_diag), "b s (h d) -> b h s d", h=h) * self.scale
-    k2, v2 = self.proj_kv(y).chunk(2, dim=-1)
-    k2, v2 = (rearrange(t, "b s f (h d) -> b h s f d", f=F, h=h) for t in (k2, v2))
-    # F = 8 logits per trajectory: a broadcast multiply + reduction streams k2 once; as the batched
-    # [1 x d] @ [d x F] products the einsum form lowers to, it is the slowest kernel of the model on MI355X
-    tattn = (k2 * q2.unsqueeze(-2)).sum(dim=-1).softmax(dim=-1)
-    val = rearrange(y, "b s f (h d) -> b h s f d", f=F, h=h) if self.use_original_code else v2
-    out = rearrange((val * tattn.unsqueeze(-1)).sum(dim=-2), "b h s d -> b s (h d)")  # same remark
+    q2p = self.proj_q(y_diag)  # [B, S, C]
+    kv = self.proj_kv(y)       # [B, S, F, 2C]: keys | values
+    Cc = q2p.shape[-1]
+    val_tok = y if self.use_original_code else kv[..., Cc:]
+    if fused and _abi.trajectory_mix_ok(q2p, kv[..., :Cc], val_tok, h):
+        # F logits per (token, head), their softmax and the weighted sum of the F trajectory tokens: one streaming
+        # pass over k2 and val (tome_trajectory_mix) instead of two multiplies, two reductions and a softmax
+        out, tattn = _abi.trajectory_mix(q2p, kv[..., :Cc], val_tok, h, self.scale)
+        tattn = tattn.to(x.dtype)
+    else:
+        q2 = rearrange(q2p, "b s (h d) -> b h s d", h=h) * self.scale
+        k2 = rearrange(kv[..., :Cc], "b s f (h d) -> b h s f d", f=F, h=h)
+        # F = 8 logits per trajectory: a broadcast multiply + reduction streams k2 once; as the batched
+        # [1 x d] @ [d x F] products the einsum form lowers to, it is the slowest kernel of the model on MI355X
+        tattn = (k2 * q2.unsqueeze(-2)).sum(dim=-1).softmax(dim=-1)
+        val = rearrange(val_tok, "b s f (h d) -> b h s f d", f=F, h=h)
+        out = rearrange((val * tattn.unsqueeze(-1)).sum(dim=-2), "b h s d -> b s (h d)")  # same remark
     out = self.proj_drop(self.proj(torch.cat((cls_out, out), dim=1)))
     keys = rearrange(k_, "(b h) (s f) d -> (b f) h s d", f=F, h=h)
     return out, tattn, keys.mean(1)
