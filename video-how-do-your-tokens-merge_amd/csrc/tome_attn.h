@@ -25,7 +25,10 @@
 // 1-3 %): one instead of two barriers per tile (double-buffered LDS), two vs four waves per SIMD, a deferred
 // rescale of O, the scores of tile t+1 computed ahead of the softmax of tile t, sixteen waves per workgroup.
 // What does: eight waves (256 queries) per workgroup sharing each staged tile (+4-9 %) -- staging K/V through
-// registers into LDS costs 18 % of the time with four.
+// registers into LDS costs 18 % of the time with four.  Where the rest goes (ablations on the eight-wave form): the
+// 33 v_exp_f32 per tile 17 %, the 32 subtractions 5 %, the 32 row-sum additions 4 %: per 64-key tile a wave
+// issues ~165 VALU + 33 transcendental + 16 conversion + 36 LDS instructions next to its 16 MFMAs (~1300 issue
+// cycles against ~1700 measured per SIMD), i.e. the softmax arithmetic, not the matrix pipe (22 % busy), bounds it.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
