@@ -889,3 +889,27 @@ def test_trajectory_mix_against_fp32_reference(B, S, F, H, dtype, tol):
         assert float((attn - want_attn).abs().max()) <= 1e-4
         assert float((out.float() - want).abs().max()) <= tol
     assert not _abi.trajectory_mix_ok(q2.float(), kv[..., :C].float(), y.float(), H)
+
+
+@pytest.mark.parametrize("growth", [0.05, 1.0, 40.0])
+@pytest.mark.parametrize("dtype,tol", [(torch.bfloat16, 2e-2), (torch.float16, 4e-3)])
+def test_prop_attention_running_maximum_moves(growth, dtype, tol):
+    """Keys ordered so that every query's logits GROW along the sequence (by `growth` per key on average): the
+    online softmax has to move its reference point tile after tile -- slowly (deferred rescale never triggers),
+    steadily (triggers regularly) and violently (an un-rescaled exponent would overflow).  Plain attention and
+    the size-biased form, against the fp32 reference."""
+    from tome import _abi
+    g = torch.Generator(device=DEV).manual_seed(17)
+    B, H, N = 2, 3, 700
+    direction = torch.randn(B, H, 1, 64, device=DEV, generator=g)
+    direction = direction / direction.norm(dim=-1, keepdim=True)
+    ramp = torch.arange(N, device=DEV).float().view(1, 1, N, 1) * growth
+    q = (8.0 * direction + 0.1 * torch.randn(B, H, N, 64, device=DEV, generator=g)).to(dtype)
+    k = (ramp * direction + 0.1 * torch.randn(B, H, N, 64, device=DEV, generator=g)).to(dtype)
+    v = torch.randn(B, H, N, 64, device=DEV, generator=g).to(dtype)
+    size = torch.randint(1, 9, (B, N, 1), device=DEV, generator=g).float()
+    for sz in (None, size):
+        out = _abi.prop_attention(q, k, v, sz, 0.125)
+        want = _attn_reference(q, k, v, None if sz is None else sz.log()[:, :, 0], 0.125, False)
+        assert torch.isfinite(out.float()).all()
+        assert float((out.float() - want).abs().max()) <= tol

@@ -24,7 +24,9 @@
 // the framework's kernel without a bias and 230-290 with one.  What was tried and makes no difference (within
 // 1-3 %): one instead of two barriers per tile (double-buffered LDS), two vs four waves per SIMD, a deferred
 // rescale of O, the scores of tile t+1 computed ahead of the softmax of tile t, sixteen waves per workgroup.
-// What does: eight waves (256 queries) per workgroup sharing each staged tile (+4-9 %) -- staging K/V through
+// What does: for plain attention the weights are taken against the current reference point before the tile's
+// maximum is known (one fma + one exp per score, no subtraction, no rescale while the maximum grows by less than
+// 2^ATT_DEFER; +2 %); eight waves (256 queries) per workgroup sharing each staged tile (+4-9 %) -- staging K/V through
 // registers into LDS costs 18 % of the time with four.  Where the rest goes (ablations on the eight-wave form): the
 // 33 v_exp_f32 per tile 17 %, the 32 subtractions 5 %, the 32 row-sum additions 4 %: per 64-key tile a wave
 // issues ~165 VALU + 33 transcendental + 16 conversion + 36 LDS instructions next to its 16 MFMAs (~1300 issue
@@ -38,6 +40,7 @@
 #define ATT_D 64        // head dim
 #define ATT_BN 64       // keys per tile
 #define ATT_KS 72       // K tile row stride in elements (144 B: conflict-free ds_read_b128 over 16 rows)
+#define ATT_DEFER 6.0f  // log2 units: weights up to 64 before the running maximum is moved
 #define ATT_VS 96       // V tile row stride in elements (192 B: conflict-free ds_read_b64_tr_b16 over 4 rows)
 
 typedef float att_f32x16 __attribute__((ext_vector_type(16)));
@@ -83,7 +86,7 @@ template <typename TX> __device__ __forceinline__ short att_bits(float f) {
     return s;
 }
 
-template <typename TX, int WAVES>
+template <typename TX, int WAVES, bool BIAS = true>
 __global__ __launch_bounds__(64 * WAVES) void k_prop_attention(AttnArgs a) {
     constexpr int ATT_BM = 32 * WAVES;  // queries per workgroup
     __shared__ __attribute__((aligned(16))) short lds_k[ATT_BN * ATT_KS];
@@ -203,44 +206,86 @@ __global__ __launch_bounds__(64 * WAVES) void k_prop_attention(AttnArgs a) {
                     vfr[kb][p][3] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(va + 8 * ATT_VS + 32));
                 }
         }
+        // Plain attention (BIAS = false, scale > 0), every key of the tile in range, not the first tile: the
+        // weights are taken against the CURRENT reference point m_run without waiting for this tile's maximum --
+        // exp2(s*sl - m_run) is one fma + one exp per score, issued as the MFMA results arrive; the maximum is
+        // reduced beside them and only checked afterwards.  While no query's maximum grew by more than 2^ATT_DEFER
+        // the weights (<= 2^ATT_DEFER instead of <= 1) are used as they are: O and l carry the same factor, the
+        // result is exact.  Otherwise (rare after the first tiles) the reference moves and the tile is redone.
+        const bool speculative = !BIAS && t > 0 && (t + 1) * ATT_BN <= a.Nk;
+        if (speculative) {
+            const float nm = -m_run;
+            float mx = -INFINITY, lsum = 0.0f;
+            att_f32x16 t0, t1;
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                t0[v] = __builtin_fmaf(s0[v], sl, nm);
+                t1[v] = __builtin_fmaf(s1[v], sl, nm);
+                s0[v] = __builtin_amdgcn_exp2f(t0[v]);
+                s1[v] = __builtin_amdgcn_exp2f(t1[v]);
+                mx = fmaxf(mx, fmaxf(t0[v], t1[v]));
+            }
+            {
+                const unsigned mb = __float_as_uint(mx);
+                const auto sw = __builtin_amdgcn_permlane32_swap(mb, mb, false, false);
+                mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+            }
+            if (!__all(mx <= ATT_DEFER)) {
+                const float grow = fmaxf(mx, 0.0f);  // this query's reference moves up by `grow` (0: stays)
+                const float alpha = __builtin_amdgcn_exp2f(-grow);
+#pragma unroll
+                for (int v = 0; v < 16; ++v) {
+                    s0[v] = __builtin_amdgcn_exp2f(t0[v] - grow);
+                    s1[v] = __builtin_amdgcn_exp2f(t1[v] - grow);
+                    o0[v] *= alpha;
+                    o1[v] *= alpha;
+                }
+                l_run *= alpha;
+                m_run += grow;
+            }
+#pragma unroll
+            for (int v = 0; v < 16; ++v) lsum += s0[v] + s1[v];
+            l_run += lsum;
+        } else {
         // ---- logits in base 2 with the per-key bias; register v <-> key (v&3) + 8*(v>>2) + 4*hf (+32)
-        float mt = -INFINITY;
+            float mt = -INFINITY;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const float4 b0 = *reinterpret_cast<const float4 *>(bias_row + 8 * g + 4 * hf);
-            const float4 b1 = *reinterpret_cast<const float4 *>(bias_row + 32 + 8 * g + 4 * hf);
-            s0[4 * g + 0] = __builtin_fmaf(s0[4 * g + 0], sl, b0.x);
-            s0[4 * g + 1] = __builtin_fmaf(s0[4 * g + 1], sl, b0.y);
-            s0[4 * g + 2] = __builtin_fmaf(s0[4 * g + 2], sl, b0.z);
-            s0[4 * g + 3] = __builtin_fmaf(s0[4 * g + 3], sl, b0.w);
-            s1[4 * g + 0] = __builtin_fmaf(s1[4 * g + 0], sl, b1.x);
-            s1[4 * g + 1] = __builtin_fmaf(s1[4 * g + 1], sl, b1.y);
-            s1[4 * g + 2] = __builtin_fmaf(s1[4 * g + 2], sl, b1.z);
-            s1[4 * g + 3] = __builtin_fmaf(s1[4 * g + 3], sl, b1.w);
-        }
+            for (int g = 0; g < 4; ++g) {
+                const float4 b0 = *reinterpret_cast<const float4 *>(bias_row + 8 * g + 4 * hf);
+                const float4 b1 = *reinterpret_cast<const float4 *>(bias_row + 32 + 8 * g + 4 * hf);
+                s0[4 * g + 0] = __builtin_fmaf(s0[4 * g + 0], sl, b0.x);
+                s0[4 * g + 1] = __builtin_fmaf(s0[4 * g + 1], sl, b0.y);
+                s0[4 * g + 2] = __builtin_fmaf(s0[4 * g + 2], sl, b0.z);
+                s0[4 * g + 3] = __builtin_fmaf(s0[4 * g + 3], sl, b0.w);
+                s1[4 * g + 0] = __builtin_fmaf(s1[4 * g + 0], sl, b1.x);
+                s1[4 * g + 1] = __builtin_fmaf(s1[4 * g + 1], sl, b1.y);
+                s1[4 * g + 2] = __builtin_fmaf(s1[4 * g + 2], sl, b1.z);
+                s1[4 * g + 3] = __builtin_fmaf(s1[4 * g + 3], sl, b1.w);
+            }
 #pragma unroll
-        for (int v = 0; v < 16; ++v) mt = fmaxf(mt, fmaxf(s0[v], s1[v]));
-        {   // the partner lane l^32 holds the other half of this query's keys: v_permlane32_swap exchanges the two
-            // halves in the vector ALU (no trip through the LDS pipeline in the middle of the softmax)
-            const unsigned mb = __float_as_uint(mt);
-            const auto sw = __builtin_amdgcn_permlane32_swap(mb, mb, false, false);
-            mt = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
-        }
-        const float m_new = fmaxf(m_run, mt);  // finite: every tile holds at least one key in range
-        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-        float lsum = 0.0f;
+            for (int v = 0; v < 16; ++v) mt = fmaxf(mt, fmaxf(s0[v], s1[v]));
+            {   // the partner lane l^32 holds the other half of this query's keys: v_permlane32_swap exchanges the two
+                // halves in the vector ALU (no trip through the LDS pipeline in the middle of the softmax)
+                const unsigned mb = __float_as_uint(mt);
+                const auto sw = __builtin_amdgcn_permlane32_swap(mb, mb, false, false);
+                mt = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+            }
+            const float m_new = fmaxf(m_run, mt);  // finite: every tile holds at least one key in range
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+            float lsum = 0.0f;
 #pragma unroll
-        for (int v = 0; v < 16; ++v) {
-            s0[v] = __builtin_amdgcn_exp2f(s0[v] - m_new);
-            s1[v] = __builtin_amdgcn_exp2f(s1[v] - m_new);
-            lsum += s0[v] + s1[v];
-        }
-        l_run = l_run * alpha + lsum;
-        m_run = m_new;
+            for (int v = 0; v < 16; ++v) {
+                s0[v] = __builtin_amdgcn_exp2f(s0[v] - m_new);
+                s1[v] = __builtin_amdgcn_exp2f(s1[v] - m_new);
+                lsum += s0[v] + s1[v];
+            }
+            l_run = l_run * alpha + lsum;
+            m_run = m_new;
 #pragma unroll
-        for (int v = 0; v < 16; ++v) {
-            o0[v] *= alpha;
-            o1[v] *= alpha;
+            for (int v = 0; v < 16; ++v) {
+                o0[v] *= alpha;
+                o1[v] *= alpha;
+            }
         }
         // ---- O^T += V^T P^T
 #pragma unroll

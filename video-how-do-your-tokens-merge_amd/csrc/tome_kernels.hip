@@ -697,13 +697,17 @@ extern "C" int tome_prop_attention(const void *q, const void *k, const void *v, 
     if (bh8 * qblocks > 0x7fffffffLL) return fail(TOME_EINVAL, "tome_prop_attention: grid too large");
     const dim3 grid((unsigned)(bh8 * qblocks));
     hipStream_t st = (hipStream_t)stream;
+    static const bool spec_env = [] { const char *e = getenv("TOME_ATTN_SPEC"); return !(e && atoi(e) == 0); }();
+    const bool plain = spec_env && !log_size && scale > 0.0f;  // no per-key term: the speculative softmax (tome_attn.h)
+#define ATT_LAUNCH(TX, W, BI) hipLaunchKernelGGL((k_prop_attention<TX, W, BI>), grid, dim3(64 * W), 0, st, a)
     if (dtype == TOME_BF16) {
-        if (waves == 8) hipLaunchKernelGGL((k_prop_attention<bf16_t, 8>), grid, dim3(512), 0, st, a);
-        else hipLaunchKernelGGL((k_prop_attention<bf16_t, 4>), grid, dim3(256), 0, st, a);
+        if (waves == 8) { if (plain) ATT_LAUNCH(bf16_t, 8, false); else ATT_LAUNCH(bf16_t, 8, true); }
+        else { if (plain) ATT_LAUNCH(bf16_t, 4, false); else ATT_LAUNCH(bf16_t, 4, true); }
     } else {
-        if (waves == 8) hipLaunchKernelGGL((k_prop_attention<f16_t, 8>), grid, dim3(512), 0, st, a);
-        else hipLaunchKernelGGL((k_prop_attention<f16_t, 4>), grid, dim3(256), 0, st, a);
+        if (waves == 8) { if (plain) ATT_LAUNCH(f16_t, 8, false); else ATT_LAUNCH(f16_t, 8, true); }
+        else { if (plain) ATT_LAUNCH(f16_t, 4, false); else ATT_LAUNCH(f16_t, 4, true); }
     }
+#undef ATT_LAUNCH
     return check_launch("k_prop_attention");
 }
 
