@@ -23,7 +23,9 @@
 // Measured on MI355X (bf16): 500-570 TFLOP/s (8x12x3137: 450-470 us, 64x12x1568: 850-900 us) against 415-500 for
 // the framework's kernel without a bias and 230-290 with one.  What was tried and makes no difference (within
 // 1-3 %): one instead of two barriers per tile (double-buffered LDS), two vs four waves per SIMD, a deferred
-// rescale of O, the scores of tile t+1 computed ahead of the softmax of tile t, sixteen waves per workgroup.
+// rescale of O, the scores of tile t+1 computed ahead of the softmax of tile t (for all waves, or only for the second wave of
+// every SIMD so that the two start each interval in different pipes), static wave priorities, sixteen waves per
+// workgroup.
 // What does: for plain attention the weights are taken against the current reference point before the tile's
 // maximum is known (one fma + one exp per score, no subtraction, no rescale while the maximum grows by less than
 // 2^ATT_DEFER; +2 %); eight waves (256 queries) per workgroup sharing each staged tile (+4-9 %) -- staging K/V through
