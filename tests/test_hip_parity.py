@@ -913,3 +913,33 @@ def test_prop_attention_running_maximum_moves(growth, dtype, tol):
         want = _attn_reference(q, k, v, None if sz is None else sz.log()[:, :, 0], 0.125, False)
         assert torch.isfinite(out.float()).all()
         assert float((out.float() - want).abs().max()) <= tol
+
+
+def test_kernels_are_deterministic():
+    """No atomics, no data-dependent reduction order anywhere on the path: the same inputs give the same bits,
+    call after call (matching, fused merge + LayerNorm, add + LayerNorm, attention with and without bias)."""
+    from tome import _abi
+    tm = _tome()
+    g = torch.Generator(device=DEV).manual_seed(99)
+    n, T, C = 6, 1568, 768
+    metric = torch.randn(n, T, 64, device=DEV, generator=g)
+    x = torch.randn(n, T, C, device=DEV, generator=g).bfloat16()
+    a = torch.randn(n, T, C, device=DEV, generator=g).bfloat16()
+    w = torch.randn(C, device=DEV, generator=g).bfloat16()
+    qkv = torch.randn(2, 700, 3, 12, 64, device=DEV, generator=g).bfloat16()
+    q, k, v = qkv.permute(2, 0, 3, 1, 4)
+    size = torch.randint(1, 5, (2, 700, 1), device=DEV, generator=g).float()
+
+    def run():
+        merge, _ = tm.bipartite_soft_matching(metric, 16)
+        p = merge.plan
+        out = [p.src_idx, p.dst_idx, p.unm_idx]
+        out += list(_abi.merge_wavg_ln(p, x, None, w, w, 1e-6, addend=a))
+        out += list(_abi.add_layernorm(x, a, w, w, 1e-6))
+        out += [_abi.prop_attention(q, k, v, None, 0.125), _abi.prop_attention(q, k, v, size, 0.125)]
+        return out
+
+    first = run()
+    for _ in range(3):
+        for t0, t1 in zip(first, run()):
+            assert torch.equal(t0, t1)
