@@ -19,7 +19,10 @@ def _block_forward(self, x, B, T, W):
     P = (x.size(1) - 1) // T  # spatial tokens per frame right now (H and W mean nothing after merging)
     m = x.size(2)
     # temporal attention over the T copies of every spatial token
-    rt = self.drop_path(self.temporal_attn(self.temporal_norm1(x[:, 1:, :].reshape(B * P, T, m)))).reshape(B, P * T, m)
+    # temporal_norm1 is per row: taken over the whole token tensor (one extra class row per clip) it can come
+    # from the previous block's fused residual + LayerNorm (finish_block below)
+    xn = C.first_norm(self, x, info, self.temporal_norm1)
+    rt = self.drop_path(self.temporal_attn(xn[:, 1:, :].reshape(B * P, T, m))).reshape(B, P * T, m)
     cls0 = x[:, :1, :]
     if torch.is_grad_enabled() and x.requires_grad:
         # the reference's op sequence (differentiable): add, transpose, three cats
@@ -53,7 +56,7 @@ def _block_forward(self, x, B, T, W):
         metric, x1, info, self.norm2,
         lambda z: self.reduction_function(metric, z, info, B, T, P), self.reduction_function is timesformer_merge, T,
         residual=res)
-    return x + self.drop_path(self.mlp(y))
+    return C.finish_block(self, x, self.drop_path(self.mlp(y)), info)
 
 
 def _attention_forward(self, x, size: torch.Tensor = None):
@@ -131,3 +134,7 @@ def apply_patch(model_wrapper, trace_source: bool = False, prop_attn: bool = Tru
             module._tome_info = model_wrapper._tome_info
             module.reduction_function = reduction_function
             C.swizzle(module.attn, "ToMeAttention", {"forward": _attention_forward})
+    if getattr(model, "attention_type", "divided_space_time") == "divided_space_time":
+        # the first LayerNorm of a divided space-time block is temporal_norm1: the previous block's last residual
+        # add hands it over fused (tome_add_layernorm)
+        C.link_next_norms(model.blocks, "temporal_norm1")
