@@ -12,7 +12,8 @@ import oracle
 import synth
 from oracle import torch_port
 
-SET = settings(max_examples=40, deadline=None, suppress_health_check=[HealthCheck.too_slow])
+SET = settings(max_examples=40, deadline=None, derandomize=True, database=None,
+               suppress_health_check=[HealthCheck.too_slow])
 
 
 @st.composite
