@@ -54,6 +54,7 @@ def parse():
     ap.add_argument("--cpu-iters", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-also", action="store_true", help="skip the secondary workloads of the `also` object")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to "
                     "rehearse N>1 on a one-GPU box)")
     return ap.parse_args()
@@ -247,25 +248,16 @@ def cpu_baseline(frames: int, r: int, clips: int, iters: int):
                       f"oracle/torch_port.py (op sequence of tome/merge.py + tome/patch/videomae.py), {dt:.1f}s"}
 
 
-def main():
-    args = parse()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N>1 must be launched through torch.distributed.run (one rank per GPU)")
+def worker(args):
+    """One rank of the job (the whole job at N=1): everything that touches the GPU happens in here."""
+    from hosts import launch
+    rank, local_rank, world = launch.check_world(args.gpus)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU path in the product)")
     dev_index = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=dev)  # "nccl" is RCCL on ROCm
-        else:
-            dist.init_process_group(backend=args.backend)
+    launch.init_process_group(args.backend, dev)  # "nccl" is RCCL on ROCm; no-op at N=1
 
     import tome
     from tome import _abi
@@ -311,16 +303,23 @@ def main():
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el.item())
+    census = launch.census(dev)  # ranks that answered + the device index of each (collective: every rank calls it)
+    if census["ranks_seen"] != world:
+        raise SystemExit(f"{census['ranks_seen']} ranks answered, {world} expected")
     total_clips = int(counts[2].item())
     assert total_clips == B * args.steps * world, (total_clips, B, args.steps, world)
 
     out = None
     if rank == 0:
         out = {
-            "metric": "clips/sec at r=16, VideoMAE-B 16x224x224 (forward with ToMe merge, merge indices bit-exact)",
+            "metric": "clips/sec at r=16, VideoMAE-B 16x224x224 (forward with ToMe merge; merge indices bit-exact against the "
+                      "fp32-arithmetic oracle, which the reference's fp32 fixtures pin)",
             "value": round(total_clips / elapsed, 2),
             "unit": "clips/s",
             "n_gpus": world,
+            "ranks_seen": census["ranks_seen"],
+            "rank_devices": census["devices"],
+            "backend": ("rccl" if args.backend == "nccl" else args.backend) if world > 1 else None,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3),
@@ -360,6 +359,18 @@ def main():
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(out), flush=True)
+
+
+def main():
+    """`python bench.py --gpus N`: under torch.distributed.run the ranks exist already (WORLD_SIZE must equal N);
+    started plainly with N > 1 the program spawns its N ranks itself -- fresh interpreters over a TCP rendezvous
+    on 127.0.0.1, as the reference's launch_job does (slowfast/utils/misc.py:402-430) -- before this process has
+    issued any GPU call, and only waits for them."""
+    from hosts import launch
+    args = parse()
+    if launch.under_launcher():
+        launch.check_world(args.gpus)
+    launch.run(worker, args.gpus, (args,))
 
 
 if __name__ == "__main__":

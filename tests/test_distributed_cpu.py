@@ -95,3 +95,71 @@ def test_clip_ensemble_meter_matches_per_clip_loop():
         assert stats["videos"] == V and stats["all_clips_seen"]
         assert abs(stats["top1_acc"] - 100.0 * (top[:, 0] == lab).float().mean().item()) < 1e-4
         assert abs(stats["top5_acc"] - 100.0 * (top == lab[:, None]).any(1).float().mean().item()) < 1e-4
+
+
+def _census_rank(out_dir):
+    """A rank as bench.py / hosts.harness run it: environment -> process group -> census -> one all-reduce."""
+    sys.path.insert(0, os.path.join(ROOT, "video-how-do-your-tokens-merge_amd"))
+    from hosts import launch
+    from hosts.evalloop import all_reduce_counts
+    rank, local, world = launch.check_world(2)
+    launch.init_process_group("gloo")
+    seen = launch.census(torch.device("cpu"))
+    counts = torch.tensor([rank + 1, 10 * (rank + 1), 7], dtype=torch.int64)
+    all_reduce_counts(counts)
+    torch.save({"rank": rank, "local": local, "world": world, "seen": seen, "counts": counts,
+                "port": os.environ["MASTER_PORT"], "addr": os.environ["MASTER_ADDR"]},
+               os.path.join(out_dir, f"census{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_launcher_spawns_its_ranks(tmp_path, monkeypatch):
+    """hosts.launch.run from a plain process (no torchrun environment) = the reference's launch_job: N fresh
+    ranks over a TCP rendezvous on 127.0.0.1, every rank sees the whole job."""
+    from hosts import launch
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        monkeypatch.delenv(k, raising=False)
+    assert not launch.under_launcher() and launch.rank_env() == (0, 0, 1)
+    launch.run(_census_rank, 2, (str(tmp_path),))
+    assert "RANK" not in os.environ  # the parent's environment is untouched
+    got = [torch.load(os.path.join(str(tmp_path), f"census{r}.pt"), weights_only=True) for r in range(2)]
+    for r, g in enumerate(got):
+        assert (g["rank"], g["local"], g["world"]) == (r, r, 2)
+        assert g["seen"] == {"ranks_seen": 2, "devices": [-1, -1]}
+        assert g["counts"].tolist() == [3, 30, 14]
+        assert g["addr"] == "127.0.0.1" and g["port"] == got[0]["port"]
+
+
+def test_launcher_refuses_a_job_of_the_wrong_size(monkeypatch):
+    from hosts import launch
+    monkeypatch.setenv("RANK", "0")
+    monkeypatch.setenv("WORLD_SIZE", "4")
+    assert launch.under_launcher()
+    with pytest.raises(SystemExit, match="WORLD_SIZE=4"):
+        launch.check_world(2)
+    monkeypatch.setenv("RANK", "5")
+    with pytest.raises(SystemExit, match="outside"):
+        launch.rank_env()
+    # bench.py applies the same check before anything else
+    sys.path.insert(0, ROOT)
+    import bench
+    monkeypatch.setenv("RANK", "0")
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2"])
+    with pytest.raises(SystemExit, match="WORLD_SIZE=4"):
+        bench.main()
+
+
+def test_bench_spawns_when_started_plainly(monkeypatch):
+    """`python bench.py --gpus 2` without a launcher environment hands `worker` to hosts.launch.run with 2 ranks
+    (and `--gpus 1` runs it in-process) -- checked without a GPU by intercepting the spawn."""
+    sys.path.insert(0, ROOT)
+    import bench
+    from hosts import launch
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        monkeypatch.delenv(k, raising=False)
+    calls = []
+    monkeypatch.setattr(launch, "run", lambda fn, n, args=(): calls.append((fn, n, args)))
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2", "--backend", "gloo"])
+    bench.main()
+    assert calls[0][0] is bench.worker and calls[0][1] == 2 and calls[0][2][0].backend == "gloo"

@@ -599,6 +599,39 @@ def test_add_layernorm(shape, dtype, tol):
     assert float(((yo.float() - ref).abs() / ref.abs().clamp(min=1.0)).max()) <= tol
 
 
+@pytest.mark.parametrize("offset", [0.0, 300.0])
+def test_layernorm_of_rows_far_from_zero(offset):
+    """Every fused LayerNorm (streaming rows, rows built by edge waves, the class-token rows of the regrouped form,
+    tome_add_layernorm) takes the variance centred on the mean (two passes over the registers): rows whose mean is
+    hundreds of standard deviations away from zero normalise like torch's LayerNorm.  E[x^2] - mean^2 in fp32 would
+    lose the variance here (std 0.25 on an offset of 300: relative 7e-7 of the squares)."""
+    from tome import _abi
+    tm = _tome()
+    dtype, C, B, F, P, r = torch.bfloat16, 768, 2, 4, 36, 6
+    # bf16 spacing near 300 is 2: build rows that are offset + small multiples of 2 so that they survive storage
+    noise = 2.0 * np.round(synth.normal_like((B, 1 + P * F, C), 501))
+    x_full = dev(offset + noise, dtype)
+    res = torch.zeros_like(x_full)
+    w = dev(1.0 + 0.1 * synth.normal_like((C,), 3), dtype)
+    b = dev(0.1 * synth.normal_like((C,), 4), dtype)
+    merge, _ = tm.bipartite_soft_matching(dev(synth.normal_like((B * F, P, 16), 505)), r)
+    got_x, got_y, _ = _abi.merge_wavg_regrouped(merge.plan, x_full, None, F, has_cls=True, ln=(w, b, 1e-6), addend=res)
+    ref = torch.nn.functional.layer_norm(got_x.float(), (C,), w.float(), b.float(), 1e-6)
+    err = ((got_y.float() - ref).abs() / ref.abs().clamp(min=1.0))
+    assert float(err.max()) <= 2 ** -7, (float(err.max()), float(err[:, 0].max()))
+    assert float(err[:, 0].max()) <= 2 ** -7  # the class-token rows on their own
+    flat = x_full.reshape(-1, C)
+    xo, yo = _abi.add_layernorm(flat, torch.zeros_like(flat), w, b, 1e-6)
+    ref2 = torch.nn.functional.layer_norm(xo.float(), (C,), w.float(), b.float(), 1e-6)
+    assert float(((yo.float() - ref2).abs() / ref2.abs().clamp(min=1.0)).max()) <= 2 ** -7
+    # contiguous form (VideoMAE / ViViT): streaming rows and rows built by edge waves
+    xc = x_full[:, 1:, :].contiguous()
+    m2, _ = tm.bipartite_soft_matching(dev(synth.normal_like((B, P * F, 16), 506)), 20)
+    gx, gy, _ = _abi.merge_wavg_ln(m2.plan, xc, None, w, b, 1e-6)
+    ref3 = torch.nn.functional.layer_norm(gx.float(), (C,), w.float(), b.float(), 1e-6)
+    assert float(((gy.float() - ref3).abs() / ref3.abs().clamp(min=1.0)).max()) <= 2 ** -7
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("n,T,C,r,cls", [(3, 197, 768, 16, True), (2, 64, 24, 30, False), (2, 392, 768, 150, False),
                                          (2, 50, 7, 9, False)])

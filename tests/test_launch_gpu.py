@@ -1,0 +1,43 @@
+"""`python bench.py --gpus 2` started plainly (no torchrun) on a one-GPU box: the program spawns its two ranks
+itself (hosts/launch.py), both compute on device 0, gloo carries the one all-reduce (RCCL needs one device per
+rank).  The same code path the driver takes on an 8-GPU node with the default backend."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(cmd):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]  # rank 0 prints ONE line
+    return json.loads(lines[0])
+
+
+@pytest.mark.gpu
+def test_bench_two_self_spawned_ranks():
+    out = _run([sys.executable, "bench.py", "--gpus", "2", "--backend", "gloo", "--batch", "4", "--steps", "2",
+                "--warmup", "1", "--no-roofline", "--no-cpu-baseline", "--no-also"])
+    assert out["n_gpus"] == 2 and out["ranks_seen"] == 2 and out["rank_devices"] == [0, 0]
+    assert out["backend"] == "gloo" and out["scaling"] == "weak" and out["value"] > 0
+    assert out["config"]["clips_per_gpu_per_step"] == 4
+
+
+@pytest.mark.gpu
+def test_model_benchmark_two_self_spawned_ranks(tmp_path):
+    """tools/model_benchmark.py with NUM_GPUS 2 (the reference's own switch, slowfast/utils/misc.py:402-430)."""
+    env_backend = dict(os.environ, TOME_DIST_BACKEND="gloo")
+    cmd = [sys.executable, "tools/model_benchmark.py", "--cfg", "configs/videomae_b_16x224.yaml", "--opts",
+           "TRAIN.ENABLE", "False", "NUM_GPUS", "2", "TOME.ENABLE", "True", "TOME.R_VALUE", "16", "TOME.PROP_ATTN",
+           "False", "MODEL_BENCHMARK.WARMUP_ITERATIONS", "1", "MODEL_BENCHMARK.ITERATIONS", "2", "TEST.BATCH_SIZE", "4"]
+    env = {k: v for k, v in env_backend.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    res = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert res["ranks_seen"] == 2 and res["devices"] == [0, 0] and res["batch"] == 4 and res["average_fps"] > 0

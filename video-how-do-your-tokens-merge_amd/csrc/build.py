@@ -43,7 +43,8 @@ def needs_build() -> bool:
     if not os.path.exists(OUT):
         return True
     t = os.path.getmtime(OUT)
-    deps = SRC + [os.path.join(HERE, h) for h in ("tome_common.h", "tome_match.h", "tome_merge.h")]
+    import glob
+    deps = SRC + sorted(glob.glob(os.path.join(HERE, "*.h")))  # every kernel header of this directory
     deps += [os.path.join(PKG, "..", "include", "tome_hip.h"), os.path.abspath(__file__)]
     return any(os.path.getmtime(d) > t for d in deps)
 

@@ -449,15 +449,16 @@ __global__ __launch_bounds__(256) void k_merge_rows_fast(const TX *__restrict__ 
                 if (a1) dst[c1] = r1;
                 float t = 0.0f, u = 0.0f;
 #pragma unroll
-                for (int e = 0; e < VEC; ++e) {
-                    const float v0 = a0 ? to_f32(p0.e[e]) : 0.0f, v1 = a1 ? to_f32(p1.e[e]) : 0.0f;
-                    t += v0 + v1;
-                    u = __fmaf_rn(v0, v0, u);
-                    u = __fmaf_rn(v1, v1, u);
-                }
+                for (int e = 0; e < VEC; ++e) t += (a0 ? to_f32(p0.e[e]) : 0.0f) + (a1 ? to_f32(p1.e[e]) : 0.0f);
                 const float fc = (float)C;
                 const float m = wave_sum(t) / fc;
-                const float rs = 1.0f / __builtin_sqrtf(fmaxf(wave_sum(u) / fc - m * m, 0.0f) + ln.eps);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) {  // centred second pass over the registers, like every other row
+                    const float d0 = a0 ? to_f32(p0.e[e]) - m : 0.0f, d1 = a1 ? to_f32(p1.e[e]) - m : 0.0f;
+                    u = __fmaf_rn(d0, d0, u);
+                    u = __fmaf_rn(d1, d1, u);
+                }
+                const float rs = 1.0f / __builtin_sqrtf(wave_sum(u) / fc + ln.eps);
                 const TX *lw = reinterpret_cast<const TX *>(ln.weight), *lb = reinterpret_cast<const TX *>(ln.bias);
                 uint4 *ydst = reinterpret_cast<uint4 *>(reinterpret_cast<TX *>(ln.y) + b * lout.outer_stride);
                 if (a0) {
@@ -636,31 +637,43 @@ __global__ __launch_bounds__(256) void k_merge_rows_fast(const TX *__restrict__ 
         if (LN) raw[it] = outv;  // keep the stored bits: LayerNorm runs on exactly what was written
     }
     if (LN) {
-        // statistics of the (up to) four rows of this wave in one pass over the registers: per-lane sums and
-        // sums of squares by row, eight independent wave reductions, var = E[x^2] - mean^2 (fp32; the tokens
-        // are 16-bit values of order one, so the cancellation costs ~1e-6 relative -- far below their epsilon)
+        // statistics of the (up to) four rows of this wave, two passes over the registers (mean, then centred
+        // variance -- a row far from zero keeps its variance, as in torch's LayerNorm): per-lane partial sums by
+        // row, four independent wave reductions per pass
         float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f, q0 = 0.0f, q1 = 0.0f, q2 = 0.0f, q3 = 0.0f;
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int rr = rowof[it];
             Pack<TX, VEC> pk;
             __builtin_memcpy(&pk, &raw[it], 16);
-            float t = 0.0f, u = 0.0f;
+            float t = 0.0f;
 #pragma unroll
-            for (int e = 0; e < VEC; ++e) {
-                const float v = to_f32(pk.e[e]);
-                t += v;
-                u = __fmaf_rn(v, v, u);
-            }
-            s0 += rr == 0 ? t : 0.0f; q0 += rr == 0 ? u : 0.0f;
-            s1 += rr == 1 ? t : 0.0f; q1 += rr == 1 ? u : 0.0f;
-            s2 += rr == 2 ? t : 0.0f; q2 += rr == 2 ? u : 0.0f;
-            s3 += rr == 3 ? t : 0.0f; q3 += rr == 3 ? u : 0.0f;
+            for (int e = 0; e < VEC; ++e) t += to_f32(pk.e[e]);
+            s0 += rr == 0 ? t : 0.0f;
+            s1 += rr == 1 ? t : 0.0f;
+            s2 += rr == 2 ? t : 0.0f;
+            s3 += rr == 3 ? t : 0.0f;
         }
         const float fc = (float)C;
         const float m0 = wave_sum(s0) / fc, m1 = wave_sum(s1) / fc, m2 = wave_sum(s2) / fc, m3 = wave_sum(s3) / fc;
-        const float v0 = fmaxf(wave_sum(q0) / fc - m0 * m0, 0.0f), v1 = fmaxf(wave_sum(q1) / fc - m1 * m1, 0.0f),
-                    v2 = fmaxf(wave_sum(q2) / fc - m2 * m2, 0.0f), v3 = fmaxf(wave_sum(q3) / fc - m3 * m3, 0.0f);
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int rr = rowof[it];
+            const float m = rr == 0 ? m0 : (rr == 1 ? m1 : (rr == 2 ? m2 : m3));
+            Pack<TX, VEC> pk;
+            __builtin_memcpy(&pk, &raw[it], 16);
+            float u = 0.0f;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                const float d = to_f32(pk.e[e]) - m;
+                u = __fmaf_rn(d, d, u);
+            }
+            q0 += rr == 0 ? u : 0.0f;
+            q1 += rr == 1 ? u : 0.0f;
+            q2 += rr == 2 ? u : 0.0f;
+            q3 += rr == 3 ? u : 0.0f;
+        }
+        const float v0 = wave_sum(q0) / fc, v1 = wave_sum(q1) / fc, v2 = wave_sum(q2) / fc, v3 = wave_sum(q3) / fc;
         const float r0 = 1.0f / __builtin_sqrtf(v0 + ln.eps), r1 = 1.0f / __builtin_sqrtf(v1 + ln.eps),
                     r2 = 1.0f / __builtin_sqrtf(v2 + ln.eps), r3 = 1.0f / __builtin_sqrtf(v3 + ln.eps);
         const TX *lw = reinterpret_cast<const TX *>(ln.weight), *lb = reinterpret_cast<const TX *>(ln.bias);
@@ -733,24 +746,38 @@ __global__ __launch_bounds__(256) void k_add_ln_rows(const TX *__restrict__ x, c
         const Pack<TX, VEC> ps = add_packs<TX, VEC>(px, pa);
         __builtin_memcpy(&raw[it], &ps, 16);
         xo[q] = raw[it];
-        float t = 0.0f, u = 0.0f;
+        float t = 0.0f;
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) {
-            const float v = to_f32(ps.e[e]);
-            t += v;
-            u = __fmaf_rn(v, v, u);
-        }
-        s0 += rr == 0 ? t : 0.0f; q0 += rr == 0 ? u : 0.0f;
-        s1 += rr == 1 ? t : 0.0f; q1 += rr == 1 ? u : 0.0f;
-        s2 += rr == 2 ? t : 0.0f; q2 += rr == 2 ? u : 0.0f;
-        s3 += rr == 3 ? t : 0.0f; q3 += rr == 3 ? u : 0.0f;
+        for (int e = 0; e < VEC; ++e) t += to_f32(ps.e[e]);
+        s0 += rr == 0 ? t : 0.0f;
+        s1 += rr == 1 ? t : 0.0f;
+        s2 += rr == 2 ? t : 0.0f;
+        s3 += rr == 3 ? t : 0.0f;
     }
     const float fc = (float)C;
     const float m0 = wave_sum(s0) / fc, m1 = wave_sum(s1) / fc, m2 = wave_sum(s2) / fc, m3 = wave_sum(s3) / fc;
-    const float r0 = 1.0f / __builtin_sqrtf(fmaxf(wave_sum(q0) / fc - m0 * m0, 0.0f) + ln.eps),
-                r1 = 1.0f / __builtin_sqrtf(fmaxf(wave_sum(q1) / fc - m1 * m1, 0.0f) + ln.eps),
-                r2 = 1.0f / __builtin_sqrtf(fmaxf(wave_sum(q2) / fc - m2 * m2, 0.0f) + ln.eps),
-                r3 = 1.0f / __builtin_sqrtf(fmaxf(wave_sum(q3) / fc - m3 * m3, 0.0f) + ln.eps);
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {  // second pass over the registers: centred variance
+        const int rr = rowof[it];
+        if (rr < 0) continue;
+        const float m = rr == 0 ? m0 : (rr == 1 ? m1 : (rr == 2 ? m2 : m3));
+        Pack<TX, VEC> pk;
+        __builtin_memcpy(&pk, &raw[it], 16);
+        float u = 0.0f;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            const float d = to_f32(pk.e[e]) - m;
+            u = __fmaf_rn(d, d, u);
+        }
+        q0 += rr == 0 ? u : 0.0f;
+        q1 += rr == 1 ? u : 0.0f;
+        q2 += rr == 2 ? u : 0.0f;
+        q3 += rr == 3 ? u : 0.0f;
+    }
+    const float r0 = 1.0f / __builtin_sqrtf(wave_sum(q0) / fc + ln.eps),
+                r1 = 1.0f / __builtin_sqrtf(wave_sum(q1) / fc + ln.eps),
+                r2 = 1.0f / __builtin_sqrtf(wave_sum(q2) / fc + ln.eps),
+                r3 = 1.0f / __builtin_sqrtf(wave_sum(q3) / fc + ln.eps);
     const TX *lw = reinterpret_cast<const TX *>(ln.weight), *lb = reinterpret_cast<const TX *>(ln.bias);
     uint4 *yo = reinterpret_cast<uint4 *>(reinterpret_cast<TX *>(ln.y) + row0 * C);
 #pragma unroll

@@ -43,6 +43,7 @@ DEFAULTS = {
     "MODEL_BENCHMARK": {"WARMUP_ITERATIONS": 0, "ITERATIONS": 0},
     "NUM_GPUS": 1,
     "NUM_SHARDS": 1,
+    "DIST_BACKEND": "nccl",  # = RCCL on ROCm (slowfast/config/defaults.py:912)
     "RNG_SEED": 0,
 }
 
@@ -143,17 +144,15 @@ _DTYPES = {"fp32": torch.float32, "bf16": torch.bfloat16, "fp16": torch.float16}
 
 
 def _setup(cfg, dtype: str):
-    """One process per GPU.  Under torch.distributed.run the rank / world come from the environment (RCCL)."""
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    """One rank = one process = one GPU (slowfast/utils/multiprocessing.py:8-62).  cfg.NUM_GPUS is the job size:
+    the ranks come from torch.distributed.run or from our own spawn (hosts/launch.py), never from this call."""
+    from . import launch
+    rank, local, world = launch.check_world(cfg.NUM_GPUS * cfg.NUM_SHARDS)
     if not torch.cuda.is_available():
         raise SystemExit("the merge path has no CPU implementation: an MI355X is required")
     dev = torch.device("cuda", local % torch.cuda.device_count())
     torch.cuda.set_device(dev)
-    if world > 1 and not dist.is_initialized():
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend=os.environ.get("TOME_DIST_BACKEND", "nccl"))
+    launch.init_process_group(os.environ.get("TOME_DIST_BACKEND", getattr(cfg, "DIST_BACKEND", "nccl")), dev)
     torch.manual_seed(cfg.RNG_SEED)
     model = build_model(cfg).to(dev).to(_DTYPES[dtype]).eval()
     return model, dev, rank, world
@@ -216,7 +215,21 @@ def perform_test(model, cfg, dev, dtype: str, rank: int = 0, world: int = 1) -> 
     return out
 
 
-def main_benchmark(argv=None) -> dict:
+def _finish(res: dict, dev, rank: int, out_path) -> dict:
+    from . import launch
+    res.update(launch.census(dev))  # ranks_seen / devices: what the job consisted of
+    if dist.is_initialized():
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(res), flush=True)
+        if out_path:
+            with open(out_path, "w") as f:
+                json.dump(res, f)
+    return res
+
+
+def _benchmark_rank(argv, out_path=None) -> dict:
     args = parse_args(argv)
     cfg = load_cfg(args.cfg_file, args.opts)
     model, dev, rank, world = _setup(cfg, args.dtype)
@@ -225,20 +238,46 @@ def main_benchmark(argv=None) -> dict:
     if rank == 0:
         print(f"Average time per frame is {res['average_frame_time_s']}(s) after {res['iterations']} iterations")
         print(f"Average fps is {res['average_fps']}(im/s) after {res['iterations']} iterations")
-        print(json.dumps(res))
-    return res
+    return _finish(res, dev, rank, out_path)
+
+
+def _run_net_rank(argv, out_path=None) -> dict:
+    args = parse_args(argv)
+    cfg = load_cfg(args.cfg_file, args.opts)
+    model, dev, rank, world = _setup(cfg, args.dtype)
+    apply_tome(model, cfg, with_threshold=True)
+    return _finish(perform_test(model, cfg, dev, args.dtype, rank, world), dev, rank, out_path)
+
+
+def _launch(rank_fn, argv) -> dict:
+    """launch_job (slowfast/utils/misc.py:402-430): NUM_GPUS > 1 -> one spawned process per GPU over a TCP
+    rendezvous, else the function is called in this process.  Nothing here touches the GPU, so the children start
+    from a parent that never initialised it.  Rank 0's result comes back through a file (a spawned rank cannot
+    return a value)."""
+    import sys
+    import tempfile
+    from . import launch
+    argv = list(sys.argv[1:] if argv is None else argv)
+    cfg = load_cfg(parse_args(argv).cfg_file, parse_args(argv).opts)
+    n = int(cfg.NUM_GPUS) * int(cfg.NUM_SHARDS)
+    if launch.under_launcher() or n <= 1:
+        return rank_fn(argv)
+    with tempfile.TemporaryDirectory() as tmp:
+        out_path = os.path.join(tmp, "rank0.json")
+        launch.run(rank_fn, n, (argv, out_path))
+        with open(out_path) as f:
+            return json.load(f)
+
+
+def main_benchmark(argv=None) -> dict:
+    return _launch(_benchmark_rank, argv)
 
 
 def main_run_net(argv=None) -> dict:
-    args = parse_args(argv)
-    cfg = load_cfg(args.cfg_file, args.opts)
+    argv_l = list(__import__("sys").argv[1:] if argv is None else argv)
+    cfg = load_cfg(parse_args(argv_l).cfg_file, parse_args(argv_l).opts)
     if cfg.TRAIN.ENABLE:
         raise SystemExit("training is outside the scope of this package (inference merge path): pass TRAIN.ENABLE False")
     if not cfg.TEST.ENABLE:
         return {}
-    model, dev, rank, world = _setup(cfg, args.dtype)
-    apply_tome(model, cfg, with_threshold=True)
-    res = perform_test(model, cfg, dev, args.dtype, rank, world)
-    if rank == 0:
-        print(json.dumps(res))
-    return res
+    return _launch(_run_net_rank, argv_l)

@@ -1,0 +1,104 @@
+"""One process per GPU, started by the program itself.
+
+The reference launches its drivers with ``torch.multiprocessing.spawn`` over a TCP rendezvous
+(slowfast/utils/misc.py:402-430 -> slowfast/utils/multiprocessing.py:8-62: ``launch_job`` spawns NUM_GPUS
+children, each calls ``init_process_group(init_method="tcp://localhost:9999", world_size, rank)`` and then the
+driver function).  Same process model here, with two differences: the parent picks a free port instead of a fixed
+one, and it must not have touched the GPU before the children start (a spawned child is a fresh interpreter;
+the parent only waits).  Under ``torch.distributed.run`` the ranks already exist and nothing is spawned.
+
+    run(worker, n_ranks, args)   in the parent: returns after all ranks have finished (or raises what a rank raised)
+    rank_env()                   in a rank: (rank, local_rank, world) from the environment
+    init_process_group(...)      in a rank: RCCL ("nccl") or gloo over 127.0.0.1, checks the world size
+"""
+from __future__ import annotations
+
+import os
+import socket
+from typing import Callable, Optional, Sequence, Tuple
+
+_ENV_KEYS = ("RANK", "LOCAL_RANK", "WORLD_SIZE")
+
+
+def free_port() -> int:
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return int(s.getsockname()[1])
+
+
+def under_launcher() -> bool:
+    """True when this process is already one rank of a job (torch.distributed.run or our own spawn)."""
+    return "RANK" in os.environ and "WORLD_SIZE" in os.environ
+
+
+def rank_env() -> Tuple[int, int, int]:
+    """(rank, local_rank, world); (0, 0, 1) for a plain single process."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", str(rank)))
+    if not 0 <= rank < world:
+        raise SystemExit(f"RANK={rank} outside WORLD_SIZE={world}")
+    return rank, local, world
+
+
+def check_world(requested: int) -> Tuple[int, int, int]:
+    """rank_env(), refusing a job whose size is not the one asked for on the command line."""
+    rank, local, world = rank_env()
+    if world != int(requested):
+        raise SystemExit(f"launched with WORLD_SIZE={world} but {requested} ranks were asked for "
+                         "(--gpus / NUM_GPUS must equal the number of ranks)")
+    return rank, local, world
+
+
+def _rank_main(local_rank: int, worker: Callable, world: int, addr: str, port: int, args: Sequence) -> None:
+    os.environ.update({"RANK": str(local_rank), "LOCAL_RANK": str(local_rank), "WORLD_SIZE": str(world),
+                       "MASTER_ADDR": addr, "MASTER_PORT": str(port)})
+    worker(*args)
+
+
+def run(worker: Callable, n_ranks: int, args: Sequence = (), port: Optional[int] = None) -> None:
+    """Run ``worker(*args)`` as ``n_ranks`` ranks of one node.  n_ranks == 1 (or an existing launcher
+    environment): called in this process.  Otherwise the ranks are spawned as fresh interpreters with
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set; the parent issues no GPU call (importing
+    torch and counting devices is not one) and joins them.  `worker` must be a module-level function."""
+    n_ranks = int(n_ranks)
+    if n_ranks < 1:
+        raise SystemExit(f"{n_ranks} ranks asked for")
+    if under_launcher() or n_ranks == 1:
+        worker(*args)
+        return
+    import torch.multiprocessing as mp
+    port = free_port() if port is None else int(port)
+    mp.spawn(_rank_main, args=(worker, n_ranks, "127.0.0.1", port, tuple(args)), nprocs=n_ranks, join=True)
+
+
+def init_process_group(backend: str, device=None) -> None:
+    """Join the job's process group (no-op for a single process).  backend "nccl" is RCCL on ROCm."""
+    import torch.distributed as dist
+    _, _, world = rank_env()
+    if world == 1 or dist.is_initialized():
+        return
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if backend == "nccl" and device is not None:
+        dist.init_process_group(backend="nccl", device_id=device)
+    else:
+        dist.init_process_group(backend=backend)
+    if dist.get_world_size() != world:
+        raise SystemExit(f"process group has {dist.get_world_size()} ranks, environment says {world}")
+
+
+def census(device) -> dict:
+    """What the job actually consists of: ranks that answered (all-reduce of ones) and the device index every
+    rank computes on (all-gather) -- reported in the result lines so a reader can see that N ranks on N
+    devices produced them."""
+    import torch
+    import torch.distributed as dist
+    idx = device.index if getattr(device, "index", None) is not None else -1
+    if not (dist.is_available() and dist.is_initialized()):
+        return {"ranks_seen": 1, "devices": [idx]}
+    one = torch.ones(1, dtype=torch.int64, device=device)
+    dist.all_reduce(one, op=dist.ReduceOp.SUM)
+    mine = torch.tensor([idx], dtype=torch.int64, device=device)
+    every = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(every, mine)
+    return {"ranks_seen": int(one.item()), "devices": [int(t.item()) for t in every]}

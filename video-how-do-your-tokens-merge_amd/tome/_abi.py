@@ -144,16 +144,12 @@ class _on_device:
         return False
 
 
-_workspaces = {}
-
-
 def _workspace(device, stream: int, nbytes: int) -> torch.Tensor:
-    key = (device.index, stream)
-    ws = _workspaces.get(key)
-    if ws is None or ws.numel() < nbytes:
-        ws = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
-        _workspaces[key] = ws
-    return ws
+    """Scratch of one matching, taken from PyTorch's caching allocator per call: the allocator hands a block back
+    only to later work of the SAME stream (or, under graph capture, keeps it inside that graph's private pool),
+    so the kernels still in flight when this tensor is released can never share it with another stream's or
+    another graph's matching -- which a process-wide cache keyed by stream handle could not guarantee."""
+    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
 
 
 def effective_r(T: int, r: int, class_token: bool, distill_token: bool) -> int:

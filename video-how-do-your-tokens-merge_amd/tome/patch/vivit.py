@@ -113,6 +113,9 @@ def apply_duplicate_patch(model, layer_to_duplicate, quantity):
     for i in range(layer_to_duplicate, layer_to_duplicate + quantity - 1):
         model.vivit.encoder.layer.insert(index=i, module=copy.deepcopy(model.vivit.encoder.layer[i]))
         C.swizzle(model.vivit.encoder.layer[i], "ToMeDuplicateVivitLayer", {"forward": _duplicate_layer_forward})
+    cfg = getattr(model.vivit, "config", None)
+    if cfg is not None and hasattr(cfg, "num_hidden_layers"):
+        cfg.num_hidden_layers += quantity  # vivit.py:209 (an HF encoder sizes head_mask from it), +quantity as there
 
 
 def apply_patch(model_wrapper, trace_source: bool = False, prop_attn: bool = True, mode: str = "merge",
