@@ -39,7 +39,7 @@ enum tome_status {
     TOME_ELAUNCH = 3     /* HIP reported a launch error (text in tome_last_error()) */
 };
 
-#define TOME_ABI_VERSION 3
+#define TOME_ABI_VERSION 4
 
 int tome_abi_version(void);
 
@@ -225,6 +225,18 @@ int tome_drop(const void *x, int dtype, int64_t n, int64_t T, int64_t C, int64_t
 int tome_unmerge(const void *x, int dtype, int64_t n, int64_t T, int64_t C, int64_t r,
                  const int64_t *src_idx, const int64_t *dst_idx, const int64_t *unm_idx, void *out,
                  tome_stream_t stream);
+
+/* tome_row_map / tome_source_init  <-  merge_source(merge, x, source=None) (merge.py:372-384) and the drop modes'
+ * `drop(eye)` (tome/patch/videomae.py:112-117): the first layer's source matrix.  The reference builds an
+ * [n,T,T] identity and merges it with mode "max"; element (o, t) of the result is 1 exactly when token t lands in
+ * merged row o, i.e. the matching's row map -- so the identity is never made.
+ *   tome_row_map      row_map [n,T1] int32 from the index tensors (same values tome_match writes when asked to)
+ *   tome_source_init  source_out [n,T-r,T] fp32, one coalesced pass; drop != 0: merged-away tokens get no row
+ */
+int tome_row_map(int64_t n, int64_t T, int64_t r, int distill_token, const int64_t *src_idx,
+                 const int64_t *dst_idx, const int64_t *unm_idx, int32_t *row_map, tome_stream_t stream);
+int tome_source_init(int64_t n, int64_t T, int64_t r, int distill_token, int drop, const int32_t *row_map,
+                     float *source_out, tome_stream_t stream);
 
 /*
  * Measurement aid (bench.py): tome_profile_enable(reps > 0) makes tome_match on the calling thread record

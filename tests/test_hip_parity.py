@@ -221,6 +221,36 @@ def test_merge_source_two_layers(case):
     np.testing.assert_array_equal(host(s2).astype(np.uint8), z[case["id"] + "_s2"])
 
 
+@pytest.mark.parametrize("n,T,r,cls,distill", [(2, 40, 8, False, False), (3, 197, 16, True, False), (1, 1568, 150, False, False),
+                                               (2, 65, 40, False, False), (2, 50, 7, True, True), (1, 3, 1, False, False)])
+def test_merge_source_first_layer_without_identity(n, T, r, cls, distill):
+    """merge_source(source=None) writes the one-hot rows from the matching's row map (tome_source_init); it must
+    equal what the reference does -- the identity merged with mode "max" (merge.py:372-384) -- element for element,
+    whether the row map came from the matching kernel or is rebuilt from the index tensors (tome_row_map); same for
+    the drop closure applied to the identity (tome/patch/videomae.py:112-117)."""
+    from tome import _abi
+    tm = _tome()
+    metric = dev(synth.normal_like((n, T, 16), 9000 + T + r))
+    x = torch.zeros(n, T, 1, device=DEV)
+    eye = torch.eye(T, device=DEV)[None].expand(n, T, T).contiguous()
+    merge, _ = tm.bipartite_soft_matching(metric, r, cls, distill)
+    want = merge(eye, mode="max")
+    got = tm.merge_source(merge, x, None)
+    assert got.dtype == torch.float32 and torch.equal(got, want)
+    assert torch.equal(got.sum(1), torch.ones(n, T, device=DEV))  # every token is in exactly one merged row
+    plan2 = _abi.match(metric, r, cls, distill, want_row_map=True)
+    assert torch.equal(plan2.row_map, merge.plan.row_map)  # tome_row_map == what k_rank_select writes
+    assert torch.equal(_abi.source_init(plan2), want)
+    drop = tm.bipartite_soft_matching_drop(metric, r, cls, distill)
+    assert torch.equal(_abi.source_init(drop.plan, drop=True), drop(eye))
+    before = torch.cuda.max_memory_allocated()
+    torch.cuda.reset_peak_memory_stats()
+    base = torch.cuda.memory_allocated()
+    tm.merge_source(merge, x, None)
+    peak = torch.cuda.max_memory_allocated() - base
+    assert peak < 1.5 * want.numel() * 4 + (1 << 20), (peak, want.numel() * 4, before)  # no [n,T,T] identity beside the result
+
+
 def test_random_merge_uses_given_scores():
     """random_merge / random_drop draw torch.rand scores (merge.py:54-57); the selection from a given
     score matrix must equal the oracle's."""
@@ -599,17 +629,19 @@ def test_add_layernorm(shape, dtype, tol):
     assert float(((yo.float() - ref).abs() / ref.abs().clamp(min=1.0)).max()) <= tol
 
 
-@pytest.mark.parametrize("offset", [0.0, 300.0])
-def test_layernorm_of_rows_far_from_zero(offset):
+@pytest.mark.parametrize("dtype,offset,step,tol", [(torch.bfloat16, 300.0, 2.0, 2 ** -7), (torch.float16, 1000.0, 0.5, 2 ** -10),
+                                                   (torch.float16, 0.0, 0.5, 2 ** -10)])
+def test_layernorm_of_rows_far_from_zero(dtype, offset, step, tol):
     """Every fused LayerNorm (streaming rows, rows built by edge waves, the class-token rows of the regrouped form,
     tome_add_layernorm) takes the variance centred on the mean (two passes over the registers): rows whose mean is
-    hundreds of standard deviations away from zero normalise like torch's LayerNorm.  E[x^2] - mean^2 in fp32 would
-    lose the variance here (std 0.25 on an offset of 300: relative 7e-7 of the squares)."""
+    hundreds of standard deviations away from zero normalise like torch's LayerNorm.  E[x^2] - mean^2 in fp32
+    loses the variance of the fp16 case (std 0.5 on an offset of 1000: the squares carry 6e-8 * 1e6 = 0.06 of
+    absolute error against a variance of 0.25)."""
     from tome import _abi
     tm = _tome()
-    dtype, C, B, F, P, r = torch.bfloat16, 768, 2, 4, 36, 6
-    # bf16 spacing near 300 is 2: build rows that are offset + small multiples of 2 so that they survive storage
-    noise = 2.0 * np.round(synth.normal_like((B, 1 + P * F, C), 501))
+    C, B, F, P, r = 768, 2, 4, 36, 6
+    # rows = offset + small multiples of the format's spacing there, so that they survive storage
+    noise = step * np.round(synth.normal_like((B, 1 + P * F, C), 501))
     x_full = dev(offset + noise, dtype)
     res = torch.zeros_like(x_full)
     w = dev(1.0 + 0.1 * synth.normal_like((C,), 3), dtype)
@@ -618,18 +650,18 @@ def test_layernorm_of_rows_far_from_zero(offset):
     got_x, got_y, _ = _abi.merge_wavg_regrouped(merge.plan, x_full, None, F, has_cls=True, ln=(w, b, 1e-6), addend=res)
     ref = torch.nn.functional.layer_norm(got_x.float(), (C,), w.float(), b.float(), 1e-6)
     err = ((got_y.float() - ref).abs() / ref.abs().clamp(min=1.0))
-    assert float(err.max()) <= 2 ** -7, (float(err.max()), float(err[:, 0].max()))
-    assert float(err[:, 0].max()) <= 2 ** -7  # the class-token rows on their own
+    assert float(err.max()) <= tol, (float(err.max()), float(err[:, 0].max()))
+    assert float(err[:, 0].max()) <= tol  # the class-token rows on their own
     flat = x_full.reshape(-1, C)
     xo, yo = _abi.add_layernorm(flat, torch.zeros_like(flat), w, b, 1e-6)
     ref2 = torch.nn.functional.layer_norm(xo.float(), (C,), w.float(), b.float(), 1e-6)
-    assert float(((yo.float() - ref2).abs() / ref2.abs().clamp(min=1.0)).max()) <= 2 ** -7
+    assert float(((yo.float() - ref2).abs() / ref2.abs().clamp(min=1.0)).max()) <= tol
     # contiguous form (VideoMAE / ViViT): streaming rows and rows built by edge waves
     xc = x_full[:, 1:, :].contiguous()
     m2, _ = tm.bipartite_soft_matching(dev(synth.normal_like((B, P * F, 16), 506)), 20)
     gx, gy, _ = _abi.merge_wavg_ln(m2.plan, xc, None, w, b, 1e-6)
     ref3 = torch.nn.functional.layer_norm(gx.float(), (C,), w.float(), b.float(), 1e-6)
-    assert float(((gy.float() - ref3).abs() / ref3.abs().clamp(min=1.0)).max()) <= 2 ** -7
+    assert float(((gy.float() - ref3).abs() / ref3.abs().clamp(min=1.0)).max()) <= tol
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])

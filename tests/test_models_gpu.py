@@ -50,8 +50,8 @@ def _build(meta):
     return tome, model.to(DEV).eval(), patch
 
 
-def _trace(tome, model, clip, r):
-    """Run the patched model, recording the plan of every matching."""
+def _trace(tome, model, clip, r, keep_metric=False):
+    """Run the patched model, recording the plan of every matching (and, on request, the metric it saw)."""
     from tome.patch import _common
     plans = []
     orig = _common.bipartite_soft_matching
@@ -59,7 +59,11 @@ def _trace(tome, model, clip, r):
     def spy(metric, r_, class_token=False, distill_token=False, mode="merge"):
         merge, unmerge = orig(metric, r_, class_token, distill_token, mode)
         if hasattr(merge, "plan"):
-            plans.append((metric.shape, merge.plan))
+            rec = (metric.shape, merge.plan)
+            if keep_metric:
+                m = metric.materialize() if hasattr(metric, "materialize") else metric
+                rec += (m.detach().double(),)
+            plans.append(rec)
         return merge, unmerge
     _common.bipartite_soft_matching = spy
     try:
@@ -71,12 +75,48 @@ def _trace(tome, model, clip, r):
     return out, plans
 
 
-@pytest.mark.parametrize("meta", G.manifest()["models"], ids=lambda m: m["name"])
-def test_patched_model_matches_reference(meta):
+class _CallCounter:
+    """Counts calls of the fused entry points of tome._abi during a forward (is the production path the one
+    that ran?)."""
+    NAMES = ("match_keys", "match", "prop_attention", "merge_wavg_ln", "merge_wavg_regrouped", "merge_wavg",
+             "add_layernorm", "trajectory_mix")
+
+    def __init__(self, monkeypatch):
+        from tome import _abi
+        self.n = {k: 0 for k in self.NAMES}
+        for k in self.NAMES:
+            monkeypatch.setattr(_abi, k, self._wrap(k, getattr(_abi, k)))
+
+    def _wrap(self, k, fn):
+        def counted(*a, **kw):
+            self.n[k] += 1
+            return fn(*a, **kw)
+        return counted
+
+
+def _patched(meta, dtype=torch.float32):
     tome, model, patch = _build(meta)
+    if meta.get("duplicate"):
+        getattr(tome.patch, "duplicate_" + meta["host"])(model, *meta["duplicate"])
     patch(model, prop_attn=meta["prop_attn"])
+    return tome, model.to(dtype)
+
+
+def _r_of(meta):
+    return list(meta["r"]) if isinstance(meta["r"], list) else meta["r"]
+
+
+@pytest.mark.parametrize("meta", G.manifest()["models"], ids=lambda m: m["name"])
+def test_patched_model_matches_reference(meta, monkeypatch):
+    """fp32 forward of the host model + tome.patch.* against the reference's own patched model (same weights by
+    name, same clip): per layer token counts, r_eff and ALL THREE index tensors exactly, final sizes exactly, logits
+    within 2e-4.  The head-dim-64 fixtures run the production matching in-model (tome_match_keys reads the per-head
+    keys of the qkv buffer; asserted by the call counter); `*_dup` fixtures go through apply_duplicate_patch."""
+    assert meta["certified"], "fixture margins below the generator's tau: re-seed it (tests/golden/generate_models.py)"
+    tome, model = _patched(meta)
+    calls = _CallCounter(monkeypatch)
     clip = torch.from_numpy(synth.uniform01(tuple(meta["clip_shape"]), meta["seed"])).to(DEV)
-    out, plans = _trace(tome, model, clip, meta["r"])
+    out, plans = _trace(tome, model, clip, _r_of(meta))
     z = np.load(os.path.join(G.GOLDEN, f"models_{meta['name']}.npz"))
     assert [s[1] for s, _ in plans] == meta["tokens"]
     assert [p.r for _, p in plans] == meta["r_eff"]
@@ -87,6 +127,84 @@ def test_patched_model_matches_reference(meta):
         np.testing.assert_array_equal(p.unm_idx.cpu().numpy()[..., 0], z[f"L{i}_unm"], err_msg=f"layer {i} unm")
     np.testing.assert_array_equal(model._tome_info["size"].cpu().numpy(), z["size"])
     np.testing.assert_allclose(out.cpu().numpy(), z["logits"], atol=2e-4, rtol=1e-4)
+    head_dim = meta["cfg"]["embed_dim"] // meta["cfg"]["num_heads"]
+    if head_dim == 64:
+        # the keys were averaged over the heads inside the matching kernel, never as a torch tensor
+        assert calls.n["match_keys"] == len(plans) and calls.n["match"] == 0, calls.n
+    if meta.get("duplicate"):
+        lay, q = meta["duplicate"]
+        blocks = model.blocks if meta["host"] == "motionformer" else model.model.blocks
+        assert len(blocks) == meta["cfg"]["depth"] + q - 1 and len(plans) == q
+
+
+_HD64 = [m for m in G.manifest()["models"] if m["cfg"]["embed_dim"] // m["cfg"]["num_heads"] == 64]
+BF16_LOGIT_TOL = 0.05  # of the largest |logit| of the fixture; see the docstring below
+
+
+@pytest.mark.parametrize("meta", _HD64, ids=lambda m: m["name"])
+def test_production_path_bf16_against_reference_fixture(meta, monkeypatch):
+    """The SAME reference fixtures, run the way the benchmark runs: bf16 weights and clips, every fused kernel on
+    (tome_match_keys, tome_prop_attention, tome_merge_wavg[_regrouped]_ln with the residual, tome_add_layernorm,
+    Motionformer's tome_trajectory_mix).  A 16-bit forward cannot reproduce fp32 decisions whose margin is below
+    its own rounding noise, so the comparison is certificate-aware:
+      * noise = max |cos_bf16 - cos_fp32| over the layer-0 score matrix, both evaluated in fp64 from the metric each
+        run handed to the matching (measured here, not assumed);
+      * a group's layer-0 SOURCE SET must equal the reference's when the gap between the r-th and (r+1)-th largest
+        row maximum exceeds 2*noise; a source's DESTINATION must equal the reference's when that row's top-2 gap
+        exceeds 2*noise;
+      * token counts and r_eff of every layer exactly; logits within BF16_LOGIT_TOL * max|logit| of the fp32
+        fixture (stated tolerance: bf16 has 8 bits of mantissa, the models are three to five blocks deep, and tokens
+        whose margin is inside the noise may merge differently)."""
+    z = np.load(os.path.join(G.GOLDEN, f"models_{meta['name']}.npz"))
+    clip32 = torch.from_numpy(synth.uniform01(tuple(meta["clip_shape"]), meta["seed"])).to(DEV)
+    tome, model32 = _patched(meta)
+    _, plans32 = _trace(tome, model32, clip32, _r_of(meta), keep_metric=True)
+    tome, model16 = _patched(meta, torch.bfloat16)
+    calls = _CallCounter(monkeypatch)
+    out16, plans16 = _trace(tome, model16, clip32.bfloat16(), _r_of(meta), keep_metric=True)
+    assert [s[1] for s, *_ in plans16] == meta["tokens"] and [p.r for _, p, _ in plans16] == meta["r_eff"]
+    # the production kernels ran
+    n_layers = len(plans16)
+    assert calls.n["prop_attention"] > 0 and calls.n["add_layernorm"] > 0, calls.n
+    assert calls.n["match_keys"] == n_layers and calls.n["match"] == 0, calls.n
+    if meta["host"] == "motionformer":
+        assert calls.n["trajectory_mix"] > 0, calls.n
+    if not meta.get("duplicate"):  # (a duplicate block only attends and merges: no LayerNorm behind that merge)
+        fused = calls.n["merge_wavg_ln"] + calls.n["merge_wavg_regrouped"]
+        assert fused == n_layers and calls.n["merge_wavg"] == 0, calls.n
+
+    # layer 0: decisions whose fp64 margin exceeds the measured bf16 noise
+    def cos(m):
+        u = m / m.norm(dim=-1, keepdim=True)
+        return u[:, ::2] @ u[:, 1::2].transpose(-1, -2)
+    s32, s16 = cos(plans32[0][2]), cos(plans16[0][2])
+    noise = float((s32 - s16).abs().max())
+    r = plans32[0][1].r
+    nm, _ = s32.max(-1)
+    snm = nm.sort(dim=-1, descending=True).values
+    set_ok = ((snm[:, r - 1] - snm[:, r]) > 2 * noise).cpu().numpy()
+    want_src, want_dst = z["L0_src"].astype(np.int64), z["L0_dst"].astype(np.int64)
+    got_src = plans16[0][1].src_idx.cpu().numpy()[..., 0]
+    got_dst = plans16[0][1].dst_idx.cpu().numpy()[..., 0]
+    checked_sets = checked_dst = 0
+    top2 = s32.topk(2, dim=-1).values
+    row_gap = (top2[..., 0] - top2[..., 1]).cpu().numpy()
+    for g in range(want_src.shape[0]):
+        if set_ok[g]:
+            assert set(got_src[g].tolist()) == set(want_src[g].tolist()), f"group {g}: source set"
+            checked_sets += 1
+        got_map = dict(zip(got_src[g].tolist(), got_dst[g].tolist()))
+        for i, j in zip(want_src[g].tolist(), want_dst[g].tolist()):
+            if i in got_map and row_gap[g, i] > 2 * noise:
+                assert got_map[i] == j, f"group {g}: destination of source row {i}"
+                checked_dst += 1
+    print(f"{meta['name']}: bf16 score noise {noise:.2e}; {checked_sets}/{want_src.shape[0]} source sets and "
+          f"{checked_dst}/{want_src.size} destinations above it, all equal to the reference")
+    assert checked_dst > 0, "no layer-0 decision lies above the bf16 noise: the fixture does not test this path"
+    ref = z["logits"]
+    err = np.abs(out16.float().cpu().numpy() - ref).max()
+    print(f"{meta['name']}: bf16 logits max |diff| {err:.3e} (largest |logit| {np.abs(ref).max():.3e})")
+    assert err <= BF16_LOGIT_TOL * np.abs(ref).max(), (err, np.abs(ref).max())
 
 
 def test_videomae_schedule_and_modes():

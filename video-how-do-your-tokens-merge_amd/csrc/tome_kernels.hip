@@ -737,6 +737,28 @@ extern "C" int tome_trajectory_mix(const void *q2, const void *k2, const void *v
     return check_launch("k_trajectory_mix");
 }
 
+extern "C" int tome_row_map(int64_t n, int64_t T, int64_t r, int distill_token, const int64_t *src_idx,
+                            const int64_t *dst_idx, const int64_t *unm_idx, int32_t *row_map, tome_stream_t stream) {
+    const int64_t T1 = (T + 1) / 2;
+    if (n <= 0 || T <= 0 || r <= 0 || r > T1 || !row_map || !src_idx || !dst_idx || (!unm_idx && T1 > r))
+        return fail(TOME_EINVAL, "tome_row_map: bad shape/pointer");
+    if (n * T1 > 0x7fffffffLL) return fail(TOME_EINVAL, "tome_row_map: too large");
+    hipLaunchKernelGGL(k_row_map, dim3((unsigned)((n * T1 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (int)n,
+                       (int)T1, (int)r, distill_token, src_idx, dst_idx, unm_idx, row_map);
+    return check_launch("k_row_map");
+}
+
+extern "C" int tome_source_init(int64_t n, int64_t T, int64_t r, int distill_token, int drop, const int32_t *row_map,
+                                float *source_out, tome_stream_t stream) {
+    const int64_t T1 = (T + 1) / 2;
+    if (n <= 0 || T <= 0 || r <= 0 || r > T1 || !row_map || !source_out)
+        return fail(TOME_EINVAL, "tome_source_init: bad shape/pointer");
+    if (n * (T - r) > 0x7fffffffLL) return fail(TOME_EINVAL, "tome_source_init: too many rows");
+    hipLaunchKernelGGL(k_source_init, dim3((unsigned)(n * (T - r))), dim3(256), 0, (hipStream_t)stream, (int)n, (int)T,
+                       (int)r, distill_token, drop ? 1 : 0, row_map, source_out);
+    return check_launch("k_source_init");
+}
+
 template <typename TX>
 static int launch_unmerge(const void *x, int64_t n, int64_t T, int64_t C, int64_t r, const int64_t *src,
                           const int64_t *dst, const int64_t *unm, void *out, hipStream_t st) {

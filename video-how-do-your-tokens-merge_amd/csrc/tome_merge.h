@@ -851,3 +851,45 @@ __global__ __launch_bounds__(256) void k_unmerge_rows(const TX *__restrict__ x, 
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Source tracking, first layer (merge.py:372-384 with source=None): the reference merges an identity matrix
+// with mode "max" -- output row o, column t is 1 exactly when token t ends up in merged row o.  That is the
+// row map of the matching, so the [n,T,T] identity and the amax over its zeros are never made:
+//   k_row_map      src/dst/unm_idx -> row_map[n,T1] (for plans that were matched without one)
+//   k_source_init  out[g,o,t] = (row of token t == o), one coalesced pass over the [n,T-r,T] result;
+//                  drop mode (merge.py:215-271 applied to the identity): merged-away tokens have no row
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_row_map(int n, int T1, int r, int distill,
+                                                 const int64_t *__restrict__ src_idx,
+                                                 const int64_t *__restrict__ dst_idx,
+                                                 const int64_t *__restrict__ unm_idx, int *__restrict__ row_map) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)n * T1) return;
+    const int g = (int)(i / T1), k = (int)(i - (int64_t)g * T1), U = T1 - r;
+    if (k < r) row_map[(int64_t)g * T1 + (int)src_idx[(int64_t)g * r + k]] = out_row_dst((int)dst_idx[(int64_t)g * r + k], U, distill);
+    else row_map[(int64_t)g * T1 + (int)unm_idx[(int64_t)g * U + (k - r)]] = out_row_unm(k - r, distill);
+}
+
+__global__ __launch_bounds__(256) void k_source_init(int n, int T_, int r, int distill, int drop,
+                                                     const int *__restrict__ row_map, float *__restrict__ out) {
+    const int To = T_ - r, T1 = (T_ + 1) >> 1, U = T1 - r;
+    const int64_t row = blockIdx.x;  // (g, o)
+    const int g = (int)(row / To), o = (int)(row - (int64_t)g * To);
+    const int *rm = row_map + (int64_t)g * T1;
+    float *orow = out + row * T_;
+    for (int t = threadIdx.x; t < T_; t += blockDim.x) {
+        int rt;
+        bool live = true;
+        if (t & 1) rt = out_row_dst(t >> 1, U, distill);
+        else {
+            rt = rm[t >> 1];
+            if (drop) {
+                bool is_dst;
+                int idx;
+                decode_out_row(rt, U, distill, is_dst, idx);
+                live = !is_dst;  // an even token that maps onto a destination row was merged away: dropped
+            }
+        }
+        orow[t] = (live && rt == o) ? 1.0f : 0.0f;
+    }
+}

@@ -21,11 +21,11 @@ SYMBOLS = (
     "tome_merge_wavg_regrouped_ln", "tome_add_layernorm", "tome_prop_attention", "tome_trajectory_mix", "tome_merge",
     "tome_drop",
     "tome_drop_regrouped",
-    "tome_unmerge",
+    "tome_unmerge", "tome_row_map", "tome_source_init",
     "tome_profile_enable", "tome_profile_read",
 )
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 DTYPES = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}
 MODES = {"sum": 0, "mean": 1, "amax": 2, "max": 2, "prod": 3, "amin": 4, "min": 4}
 
@@ -91,6 +91,10 @@ def lib() -> ctypes.CDLL:
     L.tome_drop.argtypes = [vp, i32, i64, i64, i64, i64, vp, i32, vp, vp]
     L.tome_unmerge.restype = i32
     L.tome_unmerge.argtypes = [vp, i32, i64, i64, i64, i64, vp, vp, vp, vp, vp]
+    L.tome_row_map.restype = i32
+    L.tome_row_map.argtypes = [i64, i64, i64, i32, vp, vp, vp, vp, vp]
+    L.tome_source_init.restype = i32
+    L.tome_source_init.argtypes = [i64, i64, i64, i32, i32, vp, vp, vp]
     L.tome_profile_enable.restype = i32
     L.tome_profile_enable.argtypes = [i32]
     L.tome_profile_read.restype = i32
@@ -610,6 +614,24 @@ def unmerge(plan: MatchPlan, x: torch.Tensor) -> torch.Tensor:
         rc = lib().tome_unmerge(x.data_ptr(), dtype_code(x, "x"), n, plan.T, C, plan.r, plan.src_idx.data_ptr(),
                                 plan.dst_idx.data_ptr(), plan.unm_idx.data_ptr(), out.data_ptr(), _stream(x.device))
     _check(rc, "tome_unmerge")
+    return out
+
+
+def source_init(plan: MatchPlan, drop: bool = False) -> torch.Tensor:
+    """The first layer's source matrix [n, T-r, T] fp32 (merge_source with source=None, merge.py:372-384; `drop`:
+    what the drop closure makes of the identity) written straight from the matching's row map -- no [n,T,T]
+    identity, no reduction over its zeros."""
+    with _on_device(plan.device):
+        st = _stream(plan.device)
+        if plan.row_map is None:
+            T1 = (plan.T + 1) // 2
+            plan.row_map = torch.empty((plan.n, T1), dtype=torch.int32, device=plan.device)
+            _check(lib().tome_row_map(plan.n, plan.T, plan.r, int(plan.distill_token), plan.src_idx.data_ptr(),
+                                      plan.dst_idx.data_ptr(), plan.unm_idx.data_ptr(), plan.row_map.data_ptr(), st),
+                   "tome_row_map")
+        out = torch.empty((plan.n, plan.T - plan.r, plan.T), dtype=torch.float32, device=plan.device)
+        _check(lib().tome_source_init(plan.n, plan.T, plan.r, int(plan.distill_token), int(bool(drop)),
+                                      plan.row_map.data_ptr(), out.data_ptr(), st), "tome_source_init")
     return out
 
 

@@ -251,7 +251,16 @@ def merge_wavg(merge: Callable, x: torch.Tensor, size: Optional[torch.Tensor] = 
 
 def merge_source(merge: Callable, x: torch.Tensor, source: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Source tracking: adjacency between the initial tokens and the merged groups."""
+    plan = getattr(merge, "plan", None)
     if source is None:
+        if plan is not None:
+            # merging the identity with "max" = the one-hot rows of the matching's row map: written directly
+            # (tome_source_init), the [n, T, T] identity is never allocated
+            _abi.require_device(x, "merge_source(x)")
+            if x.shape[0] != plan.n or x.shape[1] != plan.T or x.device != plan.device:
+                raise _abi.TomeHipError(f"merge_source: x {tuple(x.shape)} on {x.device} does not fit the matching "
+                                        f"({plan.n} groups of {plan.T} tokens on {plan.device})")
+            return _abi.source_init(plan)
         n, t, _ = x.shape
         source = torch.eye(t, device=x.device)[None, ...].expand(n, t, t)
     source = merge(source, mode="max")

@@ -240,15 +240,24 @@ def merge_then_norm_regrouped(metric, x_full, info, norm, unfused_reduce, is_pla
     return x_out, y_out
 
 
+def _drop_source(drop, source, n, t, device):
+    """`drop(source)` with `source = eye(T)` when None (tome/patch/videomae.py:112-117); the first layer's matrix
+    comes straight from the row map (tome_source_init), without the identity."""
+    from .. import _abi
+    plan = getattr(drop, "plan", None)
+    if source is None:
+        if plan is not None:
+            return _abi.source_init(plan, drop=True)
+        source = torch.eye(t, device=device)[None, ...].expand(n, t, t)  # nothing to drop (r clamped to 0)
+    return drop(source)
+
+
 def reduce_drop(metric, x, info, r):
     drop = bipartite_soft_matching_drop(metric, r, info["class_token"], info["distill_token"], info["mode"])
     if isinstance(drop, tuple):  # clamped r == 0: the reference returns the do_nothing pair here
         drop = drop[0]
     if info["trace_source"]:
-        if info["source"] is None:
-            n, t, _ = x.shape
-            info["source"] = torch.eye(t, device=x.device)[None, ...].expand(n, t, t)
-        info["source"] = drop(info["source"])
+        info["source"] = _drop_source(drop, info["source"], x.shape[0], x.shape[1], x.device)
     before = x.size(1)
     x = drop(x)
     info["size"] = torch.ones((x.size(0), x.size(1), 1), device=x.device)
@@ -267,9 +276,7 @@ def reduce_drop_regrouped(metric, x_full, info, r, frames: int):
         return x_full
     plan = drop.plan
     if info["trace_source"]:
-        if info["source"] is None:
-            info["source"] = torch.eye(plan.T, device=x_full.device)[None, ...].expand(plan.n, plan.T, plan.T)
-        info["source"] = drop(info["source"])
+        info["source"] = _drop_source(drop, info["source"], plan.n, plan.T, x_full.device)
     x_out = _abi.drop_regrouped(plan, x_full, frames, has_cls=True)
     info["size"] = torch.ones((plan.n, plan.T - plan.r, 1), device=x_full.device)
     if info["verbose"]:
