@@ -55,6 +55,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-also", action="store_true", help="skip the secondary workloads of the `also` object")
+    ap.add_argument("--also-quick", action="store_true", help="`also` at an eighth of the batch and few iterations (tests)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to "
                     "rehearse N>1 on a one-GPU box)")
     return ap.parse_args()
@@ -140,6 +141,8 @@ def measure_kernels(batch: int, t0: int, r: int, dev, reps: int = 10):
         # SURVEY 8d (read x and size once, write x' and size' once; bf16 tokens and sizes) + the fused residual's
         # second input and the fused norm2's own output y = LayerNorm(x') (its input never leaves the kernel)
         stats["k_merge_rows"]["bytes"] += batch * (2 * t * EMBED * 2 + t * 2 + 2 * (t - re) * EMBED * 2 + (t - re) * 2)
+        stats["k_merge_rows"]["bytes_8d"] = stats["k_merge_rows"].get("bytes_8d", 0) + \
+            batch * (t * EMBED * 2 + t * 2 + (t - re) * EMBED * 2 + (t - re) * 2)
         # --- second residual + next block's norm1 (tome_add_layernorm) on the merged tokens
         if len(stats["k_add_ln_rows"]) and t != sched[-1][0]:
             x2 = torch.empty_like(x_out)
@@ -188,6 +191,178 @@ def measure_attention(batch: int, t0: int, r: int, dev, reps: int = 5):
             "TFLOP/s": round(tf, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "frac": round(tf / MFMA_BF16_PEAK_TFLOPS, 4)}
 
 
+def _eff_r(t: int, r: int, cls: bool) -> int:
+    return max(0, min(r, (t - (1 if cls else 0)) // 2))
+
+
+def measure_merge_kernel(dev, batch: int, frames: int, tokens: int, r: int, cls: bool, reps: int = 5):
+    """The merge kernel of one model family (residual add + size-weighted merge + LayerNorm, the launch the patched
+    block makes) over the token counts of its 12 layers, HIP events around back-to-back launches on torch's current
+    stream.  frames == 1: one contiguous sequence per clip (VideoMAE; ViViT with its class token, cls=True);
+    frames > 1: `frames` interleaved groups of `tokens` spatial tokens behind a class token (TimeSformer,
+    Motionformer: tome_merge_wavg_regrouped_ln).  Returns per-forward totals: milliseconds, launches, the bytes the
+    fused launch moves (read x and the residual, write x' and LayerNorm(x'), sizes) and the merge-only bytes of
+    SURVEY.md 8d (read x and sizes once, write x' and sizes' once)."""
+    from tome import _abi
+    g = torch.Generator(device=dev).manual_seed(11)
+    n = batch * frames
+    t = tokens
+    ncls = 1 if frames > 1 else 0
+    x = torch.randn(batch, ncls + t * frames, EMBED, device=dev, generator=g).bfloat16()
+    ln_w = (1.0 + 0.1 * torch.randn(EMBED, device=dev, generator=g)).bfloat16()
+    ln_b = (0.1 * torch.randn(EMBED, device=dev, generator=g)).bfloat16()
+    size = None
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    tot = {"ms": 0.0, "launches": 0, "bytes_fused": 0, "bytes_8d": 0}
+    for _ in range(LAYERS):
+        re = _eff_r(t, r, cls)
+        if re <= 0:
+            break
+        keys = torch.randn(n, HEADS, t, HEAD_DIM, device=dev, generator=g).bfloat16()
+        plan = _abi.match_keys(keys, re, cls)
+        res = (0.1 * torch.randn(x.shape, device=dev, generator=g)).bfloat16()
+        if frames > 1:
+            def launch():
+                return _abi.merge_wavg_regrouped(plan, x, size, frames, has_cls=True, ln=(ln_w, ln_b, 1e-6), addend=res)
+        else:
+            def launch():
+                return _abi.merge_wavg_ln(plan, x, size, ln_w, ln_b, 1e-6, addend=res)
+        for _ in range(2):
+            out = launch()
+        e0.record()
+        for _ in range(reps):
+            out = launch()
+        e1.record()
+        e1.synchronize()
+        rows_in, rows_out = batch * (ncls + t * frames), batch * (ncls + (t - re) * frames)
+        tot["ms"] += e0.elapsed_time(e1) / reps
+        tot["launches"] += 1
+        tot["bytes_fused"] += 2 * rows_in * EMBED * 2 + 2 * rows_out * EMBED * 2 + n * t * 2 + n * (t - re) * 2
+        tot["bytes_8d"] += n * (t * EMBED * 2 + t * 2 + (t - re) * EMBED * 2 + (t - re) * 2)
+        x, size = out[0], out[2]
+        t -= re
+    return tot
+
+
+def merge_roofline(tot, name: str):
+    """`roofline`-shaped object of a merge kernel measured by measure_merge_kernel: achieved GB/s on the bytes the
+    fused launch moves, and on the merge-only bytes of SURVEY.md 8d next to it."""
+    sec = tot["ms"] / 1e3
+    ach, ach8 = tot["bytes_fused"] / sec / 1e9, tot["bytes_8d"] / sec / 1e9
+    return {"kernel": name, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "launches_per_step": tot["launches"],
+            "avg_launch_us": round(tot["ms"] * 1e3 / max(1, tot["launches"]), 2),
+            "bytes_fused": tot["bytes_fused"], "bytes_8d": tot["bytes_8d"], "achieved_8d": round(ach8, 1),
+            "frac_8d": round(ach8 / HBM_PEAK_GBS, 4)}
+
+
+def _throughput(model, clips, steps: int, warmup: int):
+    with torch.no_grad():
+        for _ in range(warmup):
+            model([clips])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            model([clips])
+        torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    return {"clips_per_s": round(clips.shape[0] / dt, 1), "ms_per_step": round(dt * 1e3, 3), "batch": clips.shape[0],
+            "steps": steps, "warmup": warmup}
+
+
+ALSO_FAMILIES = {
+    # name: (host builder, patch name, frames of the clip, merge groups per clip, tokens per group, class token in the
+    #        matching, yaml of the reference-style command line)
+    "videomae_b_16x224": ("videomae", 16, 1, 1568, False, "configs/videomae_b_16x224.yaml"),
+    "videomae_b_8x224": ("videomae", 8, 1, 784, False, None),
+    "timesformer_divst_8x224": ("timesformer", 8, 8, 196, False, "configs/timesformer_divst_8x224.yaml"),
+    "vivit_b_32x224": ("vivit", 32, 1, 3137, True, "configs/vivit_b_32x224.yaml"),
+    "motionformer_224_16x4": ("motionformer", 16, 8, 196, False, "configs/motionformer_224_16x4.yaml"),
+}
+
+
+def _build_family(host: str, frames: int, dev):
+    import tome
+    from hosts import motionformer, timesformer, videomae, vivit
+    torch.manual_seed(0)
+    if host == "videomae":
+        model, patch, kw = videomae.videomae_base(num_frames=frames), tome.patch.videomae, {"prop_attn": False}
+    elif host == "timesformer":
+        model, patch, kw = timesformer.timesformer_base(num_frames=frames), tome.patch.timesformer, {}
+    elif host == "vivit":
+        model, patch, kw = vivit.vivit_base(num_frames=frames), tome.patch.vivit, {}
+    else:
+        model, patch, kw = motionformer.motionformer_base(), tome.patch.motionformer, {}
+    model = model.to(dev).to(torch.bfloat16).eval()
+    patch(model, **kw)  # the reference's defaults: proportional attention on everywhere but VideoMAE
+    return model
+
+
+def also_workloads(dev, quick: bool = False):
+    """The other sizes BASELINE.json / north_star name, in the same process and JSON line as the headline so that a
+    driver-run record carries them: VideoMAE-B 8x224 r=16; TimeSformer divST 8x224 r = 8 / 16 / 32 (configs[2]);
+    ViViT-B 32x224 (3137 tokens) r=64 (configs[3]); Motionformer 224 16x4 r=16 (configs[4], one GPU's share) -- bf16,
+    random init, synthetic clips resident in HBM, each with the roofline of its family's merge kernel; and the
+    reference's own harness protocol (slowfast/utils/model_benchmark.py:20-58: batch 8, fresh torch.rand clip per
+    iteration, one event pair per forward, 5 warm-up + 100 timed) eager and replayed from a HIP graph."""
+    from hosts import harness
+    steps, warm = (3, 2) if quick else (8, 4)
+    plan = [  # (key, family, r values, clips per step)
+        ("videomae_b_8x224", "videomae_b_8x224", (16,), 128),
+        ("timesformer_divst_8x224", "timesformer_divst_8x224", (8, 16, 32), 64),
+        ("vivit_b_32x224", "vivit_b_32x224", (64,), 16),
+        ("motionformer_224_16x4", "motionformer_224_16x4", (16,), 16),
+    ]
+    out = {}
+    for key, fam, rs, batch in plan:
+        host, frames, groups, tokens, cls, _ = ALSO_FAMILIES[fam]
+        if quick:
+            batch = max(2, batch // 8)
+        model = _build_family(host, frames, dev)
+        clips = torch.rand(batch, 3, frames, 224, 224, device=dev).to(torch.bfloat16)
+        entry = {"workload": f"{fam}, bf16, random init, synthetic clips, {batch} clips per step", "tokens": tokens,
+                 "merge_groups_per_clip": groups}
+        for r in rs:
+            model.r = r
+            rec = _throughput(model, clips, steps, warm)
+            with torch.no_grad():
+                tot = measure_merge_kernel(dev, batch, groups, tokens, r, cls)
+            rec["roofline"] = merge_roofline(tot, "k_merge_rows_fast<LN> (regrouped layout)" if groups > 1
+                                             else "k_merge_rows_fast<LN>")
+            entry[f"r{r}"] = rec
+        out[key] = entry
+        del model, clips
+        torch.cuda.empty_cache()
+    # the reference's harness protocol and command line, batch 8
+    proto = {}
+    iters, wu = (10, 2) if quick else (100, 5)
+    for fam, r in (("videomae_b_16x224", 16), ("timesformer_divst_8x224", 16), ("vivit_b_32x224", 64),
+                   ("motionformer_224_16x4", 16)):
+        host, frames, _, _, _, yaml_path = ALSO_FAMILIES[fam]
+        row = {}
+        for label, r_val, graph in (("r0", 0, False), (f"r{r}_eager", r, False), (f"r{r}_hip_graph", r, True)):
+            opts = ["TRAIN.ENABLE", "False", "TEST.BATCH_SIZE", "8", "MODEL_BENCHMARK.WARMUP_ITERATIONS", str(wu),
+                    "MODEL_BENCHMARK.ITERATIONS", str(iters), "TOME.ENABLE", str(r_val > 0), "TOME.R_VALUE", str(r_val)]
+            cfg = harness.load_cfg(os.path.join(ROOT, yaml_path), opts)
+            torch.manual_seed(cfg.RNG_SEED)
+            model = harness.build_model(cfg).to(dev).to(torch.bfloat16).eval()
+            harness.apply_tome(model, cfg, with_threshold=False)
+            try:
+                res = harness.perform_benchmark(model, cfg, dev, "bf16", 1, graph=graph)
+                row[label] = round(res["clips_per_s"], 1)
+            except Exception as exc:  # a host op that cannot be captured: say so instead of hiding the row
+                row[label] = None
+                row[label + "_error"] = f"{type(exc).__name__}: {exc}"[:200]
+            del model
+            torch.cuda.empty_cache()
+        proto[fam] = row
+    out["reference_protocol_batch8"] = dict(
+        proto, unit="clips/s", protocol=f"slowfast/utils/model_benchmark.py:20-58 ({wu} warm-up + {iters} timed forwards, "
+        "batch 8, fresh torch.rand clip per iteration, one event pair per forward), tools/model_benchmark.py command "
+        "line; hip_graph = hosts/graphed.py replay")
+    return out
+
+
 def roofline_of(stats, batch: int):
     """Roofline object of the kernel that takes the most device time per forward."""
     name = max(stats, key=lambda k: stats[k]["ms"])
@@ -208,9 +383,15 @@ def roofline_of(stats, batch: int):
                 "unit": "TFLOP/s", "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4), "traffic": traffic,
                 "launches_per_step": s["launches"], "avg_launch_us": round(s["ms"] * 1e3 / s["launches"], 2)}
     achieved = s["bytes"] / sec / 1e9
-    return {"kernel": name, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "launches_per_step": s["launches"],
-            "avg_launch_us": round(s["ms"] * 1e3 / s["launches"], 2)}
+    out = {"kernel": name, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "launches_per_step": s["launches"],
+           "avg_launch_us": round(s["ms"] * 1e3 / s["launches"], 2), "bytes_fused": s["bytes"]}
+    if s.get("bytes_8d"):
+        # the same launches priced on the merge-only bytes of SURVEY.md 8d (the fused launch also reads the residual
+        # and writes the LayerNorm output, which that formula does not count)
+        out.update(bytes_8d=s["bytes_8d"], achieved_8d=round(s["bytes_8d"] / sec / 1e9, 1),
+                   frac_8d=round(s["bytes_8d"] / sec / 1e9 / HBM_PEAK_GBS, 4))
+    return out
 
 
 def usable_cpus() -> int:
@@ -352,6 +533,10 @@ def worker(args):
             out["merge_path_ms_per_step"] = round(sum(v["ms"] for v in stats.values()), 4)
             with torch.no_grad():
                 out["attention_kernel"] = measure_attention(B, t0_tokens, args.r, dev)
+        if world == 1 and not args.no_also:
+            del model, clips
+            torch.cuda.empty_cache()
+            out["also"] = also_workloads(dev, quick=args.also_quick)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.frames, args.r, args.cpu_clips, args.cpu_iters)
     if world > 1:

@@ -83,9 +83,13 @@ int tome_match(const void *metric, int dtype, int64_t n, int64_t T, int64_t D, i
  *       e.g. the k slice of the qkv projection buffer, no copy; every stride and the base must be 16-byte
  *       aligned; D must be 64.  The head mean is taken as torch does on CPU: fp32 sum in head order, one
  *       division by H, one rounding to `dtype`; everything after is tome_match.
+ * inner, stride_inner: groups interleaved inside a clip (Motionformer's '(b h) (s f) d -> (b f) h s d',
+ *       motionformer.py:143-144): group g = o * inner + f starts at o * stride_n + f * stride_inner, its tokens are
+ *       stride_t apart (inner token rows).  inner = 1 (stride_inner ignored): n independent [H,T,D] blocks.
  */
 int tome_match_keys(const void *keys, int dtype, int64_t n, int64_t H, int64_t T, int64_t D, int64_t stride_n,
-                    int64_t stride_h, int64_t stride_t, int64_t r, int class_token, int distill_token,
+                    int64_t inner, int64_t stride_inner, int64_t stride_h, int64_t stride_t, int64_t r,
+                    int class_token, int distill_token,
                     int64_t *src_idx, int64_t *dst_idx, int64_t *unm_idx, float *node_max, int32_t *row_map,
                     void *workspace, size_t workspace_bytes, tome_stream_t stream);
 
@@ -190,6 +194,17 @@ int tome_prop_attention(const void *q, const void *k, const void *v, int dtype, 
                         const int64_t *v_strides, const float *log_size, int64_t log_size_stride, int bias_skip,
                         float scale, void *out, const int64_t *out_strides, tome_stream_t stream);
 
+/* tome_prop_attention_segments  <-  the per-frame stage of ToMeTrajectoryAttention.forward
+ * (tome/patch/motionformer.py:98-121): every query attends to the keys of ONE frame at a time -- `nseg` independent
+ * key ranges of Nk keys each with their own softmax -- in ONE launch.  Segment s reads k + s*seg_strides[0],
+ * v + s*seg_strides[1], log_size + s*seg_strides[3] and writes out + s*seg_strides[2] (element offsets); the
+ * other arguments are tome_prop_attention's (no bias_skip form).  The [B*H, N, nseg*Nk] logits never exist. */
+int tome_prop_attention_segments(const void *q, const void *k, const void *v, int dtype, int64_t B, int64_t H,
+                                 int64_t N, int64_t Nk, int64_t D, const int64_t *q_strides,
+                                 const int64_t *k_strides, const int64_t *v_strides, const float *log_size,
+                                 int64_t log_size_stride, float scale, void *out, const int64_t *out_strides,
+                                 int64_t nseg, const int64_t *seg_strides, tome_stream_t stream);
+
 /*
  * tome_trajectory_mix  <-  the temporal stage of ToMeTrajectoryAttention.forward (tome/patch/motionformer.py:122-139):
  *     attn = softmax(einsum('b h s d, b h s f d -> b h s f', q2 * scale, k2)); x = einsum('b h s f, b h s f d -> b h s d', attn, v2)
@@ -210,6 +225,19 @@ int tome_trajectory_mix(const void *q2, const void *k2, const void *val, int dty
 int tome_add_layernorm(const void *x, const void *addend, int dtype, int64_t rows, int64_t C,
                        const void *ln_weight, const void *ln_bias, float eps, void *x_out, void *y_out,
                        tome_stream_t stream);
+
+/*
+ * tome_add_layernorm_regrouped  <-  the middle of TimeSformer's divided space-time ToMeBlock.forward
+ * (tome/patch/timesformer.py:24-38): the temporal attention's residual, the regrouping of the tokens for the
+ * spatial attention (class token replicated into every frame) and that attention's LayerNorm:
+ *     xt = x[:, 1:, :] + res_temporal;  x1 = cat(cls, xt)
+ *     xs = cat(cls repeated per frame, rearrange(xt, 'b (p t) m -> (b t) p m'));  y = self.norm1(xs)
+ * x [B, 1 + P*F, C], addend [B, P*F, C] -> x_out = x1 [B, 1 + P*F, C] and y_out = norm1(xs) [B*F, 1 + P, C]
+ * (16-bit, C <= 1024, C % 8 == 0): one pass, the regrouped un-normalised copy `xs` is never written.
+ */
+int tome_add_layernorm_regrouped(const void *x, const void *addend, int dtype, int64_t B, int64_t F, int64_t P,
+                                 int64_t C, const void *ln_weight, const void *ln_bias, float eps, void *x_out,
+                                 void *y_out, tome_stream_t stream);
 
 /* tome_merge  <-  merge(x, mode) closure (merge.py:75-85; hybrid :313-334 when edge_keep). */
 int tome_merge(const void *x, int dtype, int64_t n, int64_t T, int64_t C, int64_t r,

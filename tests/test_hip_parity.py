@@ -459,6 +459,39 @@ def test_match_keys_fused_head_mean(dtype, cls):
     np.testing.assert_array_equal(got.unm_idx.cpu().numpy(), plan.unm_idx)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_match_keys_interleaved_groups(dtype):
+    """Motionformer's metric (tome/patch/motionformer.py:143-144): keys regrouped '(b h) (s f) d -> (b f) h s d' and
+    averaged over the heads.  tome_match_keys takes the regrouped keys as a strided [b, f, h, s, d] VIEW of the qkv
+    buffer (inner groups) and must give what the materialised metric gives: the head mean by torch's CPU rule,
+    then the ordinary matching, bit for bit against the oracle."""
+    from einops import rearrange
+    from tome import _abi
+    from tome.merge import HeadMeanKeys
+    tm = _tome()
+    B, H, P, F, hd = 2, 12, 49, 8, 64
+    N = 1 + P * F
+    qkv = dev(synth.normal_like((B, N, 3, H, hd), 717), dtype)
+    k = qkv.permute(2, 0, 3, 1, 4)[1]  # [B, H, N, hd]
+    view = k[:, :, 1:, :].unflatten(2, (P, F)).permute(0, 3, 1, 2, 4)  # [b, f, h, s, d]
+    assert view.shape == (B, F, H, P, hd) and _abi.keys_fusable(view)
+    # the reference's own expression, on CPU
+    k_ = rearrange(k.cpu()[:, :, 1:, :], "b h n d -> (b h) n d")
+    metric = rearrange(k_, "(b h) (s f) d -> (b f) h s d", f=F, h=H).mean(1)
+    hm = HeadMeanKeys(view)
+    # (.materialize() is the framework's GPU mean: same values up to its summation order)
+    assert hm.shape == (B * F, P, hd) and torch.allclose(hm.materialize().cpu().float(), metric.float(), atol=1e-2)
+    for r in (5, 16, 40):
+        plan = oracle.match(host(metric), r, False, False)
+        got = _abi.match_keys(view, r, want_node_max=True)
+        np.testing.assert_array_equal(got.src_idx.cpu().numpy(), plan.src_idx)
+        np.testing.assert_array_equal(got.dst_idx.cpu().numpy(), plan.dst_idx)
+        np.testing.assert_array_equal(got.unm_idx.cpu().numpy(), plan.unm_idx)
+        np.testing.assert_array_equal(got.node_max.cpu().numpy().view(np.uint32), plan.node_max.view(np.uint32))
+        merge, _ = tm.bipartite_soft_matching(hm, r)
+        np.testing.assert_array_equal(merge.plan.src_idx.cpu().numpy(), plan.src_idx)
+
+
 def test_empty_and_degenerate_inputs():
     """Empty batch, single token, r larger than anything, r = 0: the do_nothing pair, as merge.py:46-47."""
     tm = _tome()
@@ -627,6 +660,28 @@ def test_add_layernorm(shape, dtype, tol):
     assert torch.equal(xo, x + a)
     ref = torch.nn.functional.layer_norm((x + a).float(), (C,), w.float(), b.float(), 1e-6)
     assert float(((yo.float() - ref).abs() / ref.abs().clamp(min=1.0)).max()) <= tol
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.bfloat16, 2 ** -7), (torch.float16, 2 ** -10)])
+@pytest.mark.parametrize("B,F,P,C", [(2, 8, 196, 768), (3, 4, 36, 128), (1, 2, 1, 64), (2, 3, 50, 1024), (5, 1, 7, 8)])
+def test_add_layernorm_regrouped(B, F, P, C, dtype, tol):
+    """tome_add_layernorm_regrouped == TimeSformer's mid-block steps (tome/patch/timesformer.py:24-38): the temporal
+    residual (class token untouched), 'b (p t) m -> (b t) p m' with the class token in front of every frame, norm1.
+    x1 bit-identical to torch's add; y within one epsilon of an fp32 LayerNorm of the regrouped stored tokens."""
+    from einops import rearrange
+    from tome import _abi
+    seed = 4400 + B * F + P + C
+    x = dev(synth.normal_like((B, 1 + P * F, C), seed), dtype)
+    a = dev(0.5 * synth.normal_like((B, P * F, C), seed + 1), dtype)
+    w = dev(1.0 + 0.1 * synth.normal_like((C,), seed + 2), dtype)
+    b = dev(0.1 * synth.normal_like((C,), seed + 3), dtype)
+    x1, y = _abi.add_layernorm_regrouped(x, a, F, w, b, 1e-6)
+    cls0, xt = x[:, :1], x[:, 1:] + a
+    assert torch.equal(x1, torch.cat((cls0, xt), 1))
+    xs = torch.cat((cls0.expand(B, F, C).reshape(B * F, 1, C), rearrange(xt, "b (p t) m -> (b t) p m", t=F)), 1)
+    assert y.shape == xs.shape
+    ref = torch.nn.functional.layer_norm(xs.float(), (C,), w.float(), b.float(), 1e-6)
+    assert float(((y.float() - ref).abs() / ref.abs().clamp(min=1.0)).max()) <= tol
 
 
 @pytest.mark.parametrize("dtype,offset,step,tol", [(torch.bfloat16, 300.0, 2.0, 2 ** -7), (torch.float16, 1000.0, 0.5, 2 ** -10),

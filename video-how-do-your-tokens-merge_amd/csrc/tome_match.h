@@ -118,8 +118,12 @@ __global__ __launch_bounds__(256) void k_unit_rows(const T *__restrict__ metric,
 // vivit.py:123-124): reads the per-head keys [n,H,T,64] straight from the attention's qkv buffer (any strides
 // with unit channel stride), averages the heads exactly as torch does on CPU -- fp32 sum in head order, one
 // division by H, one rounding to the keys' dtype -- and continues as k_unit_rows.  D = 64 only (one chunk).
+// Groups may be interleaved inside a clip's token sequence (Motionformer, motionformer.py:143-144:
+// '(b h) (s f) d -> (b f) h s d'): group g = outer * inner + f lives at outer * stride_n + f * stride_inner and its
+// token s at s * stride_t (= inner token rows), so the regrouped keys are read in place as well (inner = 1: plain).
 template <typename T>
-__global__ __launch_bounds__(256) void k_unit_rows_heads(const T *__restrict__ keys, int64_t stride_n,
+__global__ __launch_bounds__(256) void k_unit_rows_heads(const T *__restrict__ keys, int64_t stride_n, int inner,
+                                                         int64_t stride_inner,
                                                          int64_t stride_h, int64_t stride_t, int n, int H, int T_,
                                                          float *__restrict__ unitA, float *__restrict__ unitB,
                                                          int64_t groupA_f4, int64_t groupB_f4,
@@ -132,7 +136,7 @@ __global__ __launch_bounds__(256) void k_unit_rows_heads(const T *__restrict__ k
     const int64_t tk = live ? tok : ntok - 1;
     const int g = (int)(tk / T_);
     const int t = (int)(tk - (int64_t)g * T_);
-    const T *row = keys + (int64_t)g * stride_n + (int64_t)t * stride_t + 8 * b8;
+    const T *row = keys + (int64_t)(g / inner) * stride_n + (int64_t)(g % inner) * stride_inner + (int64_t)t * stride_t + 8 * b8;
     float acc[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) acc[e] = 0.0f;

@@ -893,3 +893,130 @@ __global__ __launch_bounds__(256) void k_source_init(int n, int T_, int r, int d
         orow[t] = (live && rt == o) ? 1.0f : 0.0f;
     }
 }
+
+// k_add_ln_regroup: the middle of TimeSformer's divided space-time block (tome/patch/timesformer.py:24-38):
+//     xt = x[:, 1:] + temporal_fc(res_temporal)                       residual of the temporal attention
+//     xs = cat(cls replicated per frame, 'b (p t) m -> (b t) p m' of xt) spatial regrouping
+//     ... self.norm1(xs)
+// One pass: x1 = cat(cls, xt) in the token layout [B, 1 + P*F, C], and y = norm1 of every row written straight to
+// its place in the regrouped [B*F, 1 + P, C] tensor (a LayerNorm is per row, so normalising before the permutation
+// is the same thing); the class row is normalised once and stored F times.  Replaces an add, a strided copy and a
+// LayerNorm (7 passes over the tokens) by 2 reads + 2 writes.  Same arithmetic as k_add_ln_rows.
+template <typename TX, int NIT>
+__global__ __launch_bounds__(256) void k_add_ln_regroup(const TX *__restrict__ x, const TX *__restrict__ a, int B, int F,
+                                                        int P, int C, int R, int cpr, LnArgs ln,
+                                                        TX *__restrict__ xout) {
+    constexpr int VEC = 16 / sizeof(TX);
+    const int lane = threadIdx.x & 63;
+    const int64_t w = (int64_t)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int N = 1 + P * F;
+    const int64_t rows = (int64_t)B * N;
+    const int64_t row0 = w * R;
+    if (row0 >= rows) return;
+    const int nrow = (int)((rows - row0) < R ? (rows - row0) : R);
+    const int total = nrow * cpr;
+    // per-row facts (wave-uniform): addend row (-1: class token, nothing is added) and the row of y
+    int64_t arow[FAST_MAXR], yrow[FAST_MAXR];
+#pragma unroll
+    for (int rr = 0; rr < FAST_MAXR; ++rr) {
+        const int64_t gr = row0 + (rr < nrow ? rr : 0);
+        const int64_t b = gr / N;
+        const int k = (int)(gr - b * N);
+        if (k == 0) {
+            arow[rr] = -1;
+            yrow[rr] = b * F * (1 + P);  // frame 0; frames 1..F-1 follow at (1+P) rows each
+        } else {
+            const int p = (k - 1) / F, t = (k - 1) - p * F;
+            arow[rr] = b * (int64_t)(P * F) + (k - 1);
+            yrow[rr] = (b * F + t) * (int64_t)(1 + P) + 1 + p;
+        }
+    }
+    const uint4 *xs = reinterpret_cast<const uint4 *>(x + row0 * C);
+    uint4 raw[NIT], rawa[NIT];
+    int rowof[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int q = it * WAVE + lane;
+        const int rr = (q >= cpr) + (q >= 2 * cpr) + (q >= 3 * cpr);
+        rowof[it] = q < total ? rr : -1;
+        if (q >= total) continue;
+        raw[it] = xs[q];
+        const int64_t ar = rr == 0 ? arow[0] : (rr == 1 ? arow[1] : (rr == 2 ? arow[2] : arow[3]));
+        if (ar >= 0) rawa[it] = reinterpret_cast<const uint4 *>(a + ar * C)[q - rr * cpr];
+    }
+    uint4 *xo = reinterpret_cast<uint4 *>(xout + row0 * C);
+    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f, q0 = 0.0f, q1 = 0.0f, q2 = 0.0f, q3 = 0.0f;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int rr = rowof[it];
+        if (rr < 0) continue;
+        const int q = it * WAVE + lane;
+        const int64_t ar = rr == 0 ? arow[0] : (rr == 1 ? arow[1] : (rr == 2 ? arow[2] : arow[3]));
+        Pack<TX, VEC> ps;
+        __builtin_memcpy(&ps, &raw[it], 16);
+        if (ar >= 0) {
+            Pack<TX, VEC> pa;
+            __builtin_memcpy(&pa, &rawa[it], 16);
+            ps = add_packs<TX, VEC>(ps, pa);
+            __builtin_memcpy(&raw[it], &ps, 16);
+        }
+        xo[q] = raw[it];
+        float t = 0.0f;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) t += to_f32(ps.e[e]);
+        s0 += rr == 0 ? t : 0.0f;
+        s1 += rr == 1 ? t : 0.0f;
+        s2 += rr == 2 ? t : 0.0f;
+        s3 += rr == 3 ? t : 0.0f;
+    }
+    const float fc = (float)C;
+    const float m0 = wave_sum(s0) / fc, m1 = wave_sum(s1) / fc, m2 = wave_sum(s2) / fc, m3 = wave_sum(s3) / fc;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int rr = rowof[it];
+        if (rr < 0) continue;
+        const float m = rr == 0 ? m0 : (rr == 1 ? m1 : (rr == 2 ? m2 : m3));
+        Pack<TX, VEC> pk;
+        __builtin_memcpy(&pk, &raw[it], 16);
+        float u = 0.0f;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            const float d = to_f32(pk.e[e]) - m;
+            u = __fmaf_rn(d, d, u);
+        }
+        q0 += rr == 0 ? u : 0.0f;
+        q1 += rr == 1 ? u : 0.0f;
+        q2 += rr == 2 ? u : 0.0f;
+        q3 += rr == 3 ? u : 0.0f;
+    }
+    const float r0 = 1.0f / __builtin_sqrtf(wave_sum(q0) / fc + ln.eps),
+                r1 = 1.0f / __builtin_sqrtf(wave_sum(q1) / fc + ln.eps),
+                r2 = 1.0f / __builtin_sqrtf(wave_sum(q2) / fc + ln.eps),
+                r3 = 1.0f / __builtin_sqrtf(wave_sum(q3) / fc + ln.eps);
+    const TX *lw = reinterpret_cast<const TX *>(ln.weight), *lb = reinterpret_cast<const TX *>(ln.bias);
+    TX *yb = reinterpret_cast<TX *>(ln.y);
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int rr = rowof[it];
+        if (rr < 0) continue;
+        const int q = it * WAVE + lane;
+        const int cc = q - rr * cpr;
+        const float m = rr == 0 ? m0 : (rr == 1 ? m1 : (rr == 2 ? m2 : m3));
+        const float rs = rr == 0 ? r0 : (rr == 1 ? r1 : (rr == 2 ? r2 : r3));
+        const int64_t ar = rr == 0 ? arow[0] : (rr == 1 ? arow[1] : (rr == 2 ? arow[2] : arow[3]));
+        const int64_t yr = rr == 0 ? yrow[0] : (rr == 1 ? yrow[1] : (rr == 2 ? yrow[2] : yrow[3]));
+        Pack<TX, VEC> pk;
+        __builtin_memcpy(&pk, &raw[it], 16);
+        float w8[VEC], b8[VEC];
+        load_pack<TX, VEC>(lw + cc * VEC, w8);
+        load_pack<TX, VEC>(lb + cc * VEC, b8);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) pk.e[e] = from_f32<TX>((to_f32(pk.e[e]) - m) * rs * w8[e] + b8[e]);
+        uint4 yv;
+        __builtin_memcpy(&yv, &pk, 16);
+        uint4 *yp = reinterpret_cast<uint4 *>(yb + yr * C) + cc;
+        *yp = yv;
+        if (ar < 0)  // class token: the same normalised row in front of every frame's tokens
+            for (int t = 1; t < F; ++t) yp[(int64_t)t * (1 + P) * cpr] = yv;
+    }
+}

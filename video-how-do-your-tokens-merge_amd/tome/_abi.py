@@ -18,7 +18,7 @@ SYMBOLS = (
     "tome_abi_version", "tome_last_error", "tome_effective_r", "tome_match_workspace_bytes", "tome_match",
     "tome_match_keys",
     "tome_match_scores", "tome_edge_keep", "tome_merge_wavg", "tome_merge_wavg_ln", "tome_merge_wavg_regrouped",
-    "tome_merge_wavg_regrouped_ln", "tome_add_layernorm", "tome_prop_attention", "tome_trajectory_mix", "tome_merge",
+    "tome_merge_wavg_regrouped_ln", "tome_add_layernorm", "tome_add_layernorm_regrouped", "tome_prop_attention", "tome_prop_attention_segments", "tome_trajectory_mix", "tome_merge",
     "tome_drop",
     "tome_drop_regrouped",
     "tome_unmerge", "tome_row_map", "tome_source_init",
@@ -59,8 +59,8 @@ def lib() -> ctypes.CDLL:
     L.tome_match.restype = i32
     L.tome_match.argtypes = [vp, i32, i64, i64, i64, i64, i64, i64, i32, i32, vp, vp, vp, vp, vp, vp, sz, vp]
     L.tome_match_keys.restype = i32
-    L.tome_match_keys.argtypes = [vp, i32, i64, i64, i64, i64, i64, i64, i64, i64, i32, i32, vp, vp, vp, vp, vp, vp, sz,
-                                  vp]
+    L.tome_match_keys.argtypes = [vp, i32, i64, i64, i64, i64, i64, i64, i64, i64, i64, i64, i32, i32, vp, vp, vp, vp,
+                                  vp, vp, sz, vp]
     L.tome_match_scores.restype = i32
     L.tome_match_scores.argtypes = [vp, i64, i64, i64, i32, i32, vp, vp, vp, vp, vp, vp, sz, vp]
     L.tome_edge_keep.restype = i32
@@ -78,11 +78,16 @@ def lib() -> ctypes.CDLL:
                                                ctypes.c_float, vp, vp, vp, vp, vp, vp]
     L.tome_add_layernorm.restype = i32
     L.tome_add_layernorm.argtypes = [vp, vp, i32, i64, i64, vp, vp, ctypes.c_float, vp, vp, vp]
+    L.tome_add_layernorm_regrouped.restype = i32
+    L.tome_add_layernorm_regrouped.argtypes = [vp, vp, i32, i64, i64, i64, i64, vp, vp, ctypes.c_float, vp, vp, vp]
     L.tome_merge.restype = i32
     L.tome_merge.argtypes = [vp, i32, i64, i64, i64, i64, vp, vp, vp, i32, i32, vp, vp, vp]
     L.tome_prop_attention.restype = i32
     L.tome_prop_attention.argtypes = [vp, vp, vp, i32, i64, i64, i64, i64, i64, vp, vp, vp, vp, i64, i32, ctypes.c_float,
                                       vp, vp, vp]
+    L.tome_prop_attention_segments.restype = i32
+    L.tome_prop_attention_segments.argtypes = [vp, vp, vp, i32, i64, i64, i64, i64, i64, vp, vp, vp, vp, i64,
+                                               ctypes.c_float, vp, vp, i64, vp, vp]
     L.tome_trajectory_mix.restype = i32
     L.tome_trajectory_mix.argtypes = [vp, vp, vp, i32, i64, i64, i64, i64, i64, i64, i64, ctypes.c_float, vp, vp, vp]
     L.tome_drop_regrouped.restype = i32
@@ -221,20 +226,31 @@ def match(metric: torch.Tensor, r: int, class_token=False, distill_token=False, 
 
 
 def keys_fusable(keys: torch.Tensor) -> bool:
-    """Can tome_match_keys read this [n,H,T,64] key tensor in place?"""
-    if keys.dim() != 4 or keys.shape[-1] != 64 or keys.stride(3) != 1 or keys.dtype not in DTYPES or not keys.is_cuda:
+    """Can tome_match_keys read these per-head keys in place?  [n, H, T, 64], or [outer, inner, H, T, 64] when the
+    groups are interleaved inside a clip (Motionformer's '(s f)' regrouping), any strides with contiguous channels
+    and 16-byte aligned rows."""
+    if keys.dim() not in (4, 5) or keys.shape[-1] != 64 or keys.stride(-1) != 1 or keys.dtype not in DTYPES \
+            or not keys.is_cuda:
         return False
     es = keys.element_size()
-    return keys.data_ptr() % 16 == 0 and all((keys.stride(d) * es) % 16 == 0 for d in range(3))
+    return keys.data_ptr() % 16 == 0 and all((keys.stride(d) * es) % 16 == 0 for d in range(keys.dim() - 1))
 
 
 def match_keys(keys: torch.Tensor, r: int, class_token=False, distill_token=False, want_node_max=False,
                want_row_map=False, checked: bool = False) -> Optional[MatchPlan]:
-    """tome_match_keys on per-head keys [n,H,T,64] (metric = keys.mean(1) is never materialised)."""
+    """tome_match_keys on per-head keys [n,H,T,64] or [outer,inner,H,T,64] (group = outer*inner + inner index;
+    the metric = keys.mean(heads) is never materialised)."""
     if not checked and not keys_fusable(keys):
         require_device(keys, "match_keys(keys)")
         raise TomeHipError(f"match_keys: keys {tuple(keys.shape)} strides {keys.stride()} are not readable in place")
-    n, H, T, D = keys.shape
+    if keys.dim() == 5:
+        outer, inner, H, T, D = keys.shape
+        n = outer * inner
+        s_n, s_in, s_h, s_t = keys.stride()[:4]
+    else:
+        n, H, T, D = keys.shape
+        inner, s_in = 1, 0
+        s_n, s_h, s_t = keys.stride()[:3]
     re = effective_r(T, r, class_token, distill_token)
     if re <= 0 or n == 0:
         return None
@@ -245,8 +261,8 @@ def match_keys(keys: torch.Tensor, r: int, class_token=False, distill_token=Fals
         nbytes = L.tome_match_workspace_bytes(n, T, D)
         ws = _workspace(dev, st, nbytes)
         plan = _alloc_plan(n, T, re, class_token, distill_token, dev, want_node_max, want_row_map)
-        rc = L.tome_match_keys(keys.data_ptr(), DTYPES[keys.dtype], n, H, T, D, keys.stride(0), keys.stride(1),
-                               keys.stride(2), int(r), int(bool(class_token)), int(bool(distill_token)),
+        rc = L.tome_match_keys(keys.data_ptr(), DTYPES[keys.dtype], n, H, T, D, s_n, inner, s_in, s_h, s_t, int(r),
+                               int(bool(class_token)), int(bool(distill_token)),
                                plan.src_idx.data_ptr(), plan.dst_idx.data_ptr(), plan.unm_idx.data_ptr(),
                                _ptr(plan.node_max), _ptr(plan.row_map), ws.data_ptr(), ws.numel(), st)
     _check(rc, "tome_match_keys")
@@ -405,6 +421,30 @@ def add_layernorm(x: torch.Tensor, addend: torch.Tensor, weight: torch.Tensor, b
     return x_out, y_out
 
 
+def add_layernorm_regrouped(x: torch.Tensor, addend: torch.Tensor, frames: int, weight: torch.Tensor,
+                            bias: torch.Tensor, eps: float):
+    """TimeSformer's mid-block step in one launch: x [B, 1 + P*F, C] (class token first), addend [B, P*F, C] ->
+    (x1, y) with x1 = cat(cls, x[:, 1:] + addend) and y = LayerNorm of the tokens regrouped
+    'b (p t) m -> (b t) p m' with the class token in front of every frame: [B*F, 1 + P, C]."""
+    require_device(x, "add_layernorm_regrouped(x)")
+    B, N, C = x.shape
+    F = int(frames)
+    P = (N - 1) // F
+    if N != 1 + P * F or tuple(addend.shape) != (B, P * F, C) or addend.dtype != x.dtype or addend.device != x.device:
+        raise TomeHipError(f"add_layernorm_regrouped: x {tuple(x.shape)} / addend {tuple(addend.shape)} do not hold a "
+                           f"class token and {F} frames of tokens")
+    x = x if x.is_contiguous() else x.contiguous()
+    addend = addend if addend.is_contiguous() else addend.contiguous()
+    x_out = torch.empty_like(x)
+    y_out = torch.empty((B * F, 1 + P, C), dtype=x.dtype, device=x.device)
+    with _on_device(x.device):
+        rc = lib().tome_add_layernorm_regrouped(x.data_ptr(), addend.data_ptr(), dtype_code(x, "x"), B, F, P, C,
+                                                weight.data_ptr(), bias.data_ptr(), float(eps), x_out.data_ptr(),
+                                                y_out.data_ptr(), _stream(x.device))
+    _check(rc, "tome_add_layernorm_regrouped")
+    return x_out, y_out
+
+
 def merge_wavg_regrouped(plan: MatchPlan, x_full: torch.Tensor, size: Optional[torch.Tensor], frames: int,
                          has_cls: bool = True, ln=None, addend: Optional[torch.Tensor] = None,
                          log_size: bool = False):
@@ -546,6 +586,39 @@ def prop_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, size: Opti
                                        out.data_ptr(), ostr, _stream(q.device))
     _check(rc, "tome_prop_attention")
     return result
+
+
+def prop_attention_segments(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, nseg: int, scale: float,
+                            log_bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Per-segment attention in one launch: queries q [B, H, N, 64]; keys / values [B, H, nseg*P, 64] views whose
+    rows [s*P, (s+1)*P) form segment s; every query takes softmax(q k_s^T * scale + log_bias_s) v_s for each
+    segment separately (Motionformer: the P keys of one frame, motionformer.py:98-121).  log_bias: fp32
+    [B, nseg*P] (contiguous rows) or None.  Returns y [B, N, nseg, H*64]."""
+    for t, name in ((q, "q"), (k, "k"), (v, "v")):
+        require_device(t, f"prop_attention_segments({name})")
+        if not prop_attention_ok(t) or t.dtype != q.dtype or t.device != q.device:
+            raise TomeHipError(f"prop_attention_segments: {name} must be a [B, H, N, 64] 16-bit view with 16-byte "
+                               f"aligned rows, got {tuple(t.shape)} {t.dtype} strides {t.stride()}")
+    B, H, N, D = q.shape
+    nseg = int(nseg)
+    if k.shape != v.shape or k.shape[:2] != (B, H) or nseg < 1 or k.shape[2] % nseg:
+        raise TomeHipError(f"prop_attention_segments: q {tuple(q.shape)}, k {tuple(k.shape)}, v {tuple(v.shape)}, "
+                           f"{nseg} segments do not match")
+    P = k.shape[2] // nseg
+    if log_bias is not None and (tuple(log_bias.shape) != (B, nseg * P) or log_bias.dtype != torch.float32
+                                 or log_bias.stride(1) != 1 or log_bias.device != q.device):
+        raise TomeHipError(f"prop_attention_segments: log_bias must be an fp32 {(B, nseg * P)} view with contiguous rows")
+    y = torch.empty((B, N, nseg, H * D), dtype=q.dtype, device=q.device)
+    strides = [(ctypes.c_int64 * 3)(*t.stride()[:3]) for t in (q, k, v)]
+    ostr = (ctypes.c_int64 * 3)(y.stride(0), D, y.stride(1))  # {batch, head, token}
+    seg = (ctypes.c_int64 * 4)(P * k.stride(2), P * v.stride(2), y.stride(2), P)
+    with _on_device(q.device):
+        rc = lib().tome_prop_attention_segments(q.data_ptr(), k.data_ptr(), v.data_ptr(), dtype_code(q, "q"), B, H, N, P,
+                                                D, strides[0], strides[1], strides[2], _ptr(log_bias),
+                                                0 if log_bias is None else log_bias.stride(0), float(scale),
+                                                y.data_ptr(), ostr, nseg, seg, _stream(q.device))
+    _check(rc, "tome_prop_attention_segments")
+    return y
 
 
 def trajectory_mix_ok(q2: torch.Tensor, k2: torch.Tensor, val: torch.Tensor, heads: int) -> bool:

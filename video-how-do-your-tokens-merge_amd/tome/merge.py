@@ -32,27 +32,36 @@ def do_nothing(x, mode=None):
 
 class HeadMeanKeys:
     """The metric ``k.mean(1)`` kept as a promise: holds the per-head keys [n,H,T,64] (a view of the attention's
-    qkv buffer).  The matching functions of this module read the keys in place (tome_match_keys: head mean,
-    unit vectors, similarity in one pass over them); anything else that wants the tensor calls
-    ``.materialize()``.  Shape queries behave like the metric's."""
+    qkv buffer) -- or [outer,inner,H,T,64] when the merge groups are interleaved inside a clip's sequence
+    (Motionformer's ``'(b h) (s f) d -> (b f) h s d'``; group = outer*inner + inner index).  The matching functions
+    of this module read the keys in place (tome_match_keys: head mean, unit vectors, similarity in one pass over
+    them); anything else that wants the tensor calls ``.materialize()``.  Shape queries behave like the metric's."""
 
     def __init__(self, keys: torch.Tensor):
+        if keys.dim() not in (4, 5):
+            raise ValueError(f"HeadMeanKeys: [n,H,T,D] or [outer,inner,H,T,D] expected, got {tuple(keys.shape)}")
         self.keys = keys
 
     @property
     def shape(self):
-        n, _, t, d = self.keys.shape
+        *lead, _, t, d = self.keys.shape
+        n = lead[0] * (lead[1] if len(lead) == 2 else 1)
         return torch.Size((n, t, d))
 
     @property
     def device(self):
         return self.keys.device
 
+    @property
+    def dtype(self):
+        return self.keys.dtype
+
     def size(self, dim=None):
         return self.shape if dim is None else self.shape[dim]
 
     def materialize(self) -> torch.Tensor:
-        return self.keys.mean(1)
+        m = self.keys.mean(-3)
+        return m if m.dim() == 3 else m.reshape(-1, m.shape[-2], m.shape[-1])
 
 
 def _scores_for_random(metric: torch.Tensor) -> torch.Tensor:

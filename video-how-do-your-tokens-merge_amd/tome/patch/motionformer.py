@@ -9,6 +9,7 @@ from einops import rearrange
 
 from . import _common as C
 from .. import _abi
+from ..merge import HeadMeanKeys
 
 
 def _block_forward(self, x, seq_len=196, num_frames=8, approx="none", num_landmarks=128):
@@ -44,26 +45,25 @@ def _trajectory_forward(self, x, seq_len=196, num_frames=8, approx="none", num_l
     hd = qkv.shape[-1] // (3 * h)
     heads = qkv.view(B, N, 3, h, hd).permute(2, 0, 3, 1, 4)  # q, k, v as [B, h, N, hd] views of the projection
     fused = (C._ATTN_KERNEL and not (self.training and self.attn_drop.p > 0.0) and all(_abi.prop_attention_ok(t) for t in heads))
-    q, k, v = (rearrange(t, "b n (h d) -> (b h) n d", h=h) for t in qkv.chunk(3, dim=-1))
-    (cls_q, q_), (cls_k, k_), (cls_v, v_) = ((t[:, 0:1], t[:, 1:]) for t in (q, k, v))
-    cls_out = rearrange(qkv_attn(cls_q * self.scale, k, v), "(b h) f d -> b f (h d)", f=1, h=h)
     # flat per-key bias in the reference's '(s f)' order (motionformer.py:107-111): key j of the (f n)-ordered
     # sequence gets log(size) of (s = j // F, f = j % F)
     log_flat = None
     if size is not None:
         log_flat = rearrange(_abi.log_of_size(size), "(b f) s i -> b (s f) i", f=F)[:, :, 0]
     if fused:
-        # every token attends to the P keys of ONE frame at a time (softmax per frame): F launches of the attention
-        # kernel, queries and keys read in place from the qkv buffer, each writing its slice of y '(b) s f (h d)';
-        # the [B*h, N, N] logits, their softmax and the attn @ v product never exist
-        y = torch.empty((B, N - 1, F, h * hd), dtype=x.dtype, device=x.device)
+        # the class token attends to every token, sizes ignored (motionformer.py:54): the attention kernel with one
+        # query per head, read in place
+        cls_out = _abi.prop_attention(heads[0][:, :, :1], heads[1], heads[2], None, self.scale)
+        # every token attends to the P keys of ONE frame at a time (softmax per frame): ONE launch of the segmented
+        # attention kernel, queries and keys read in place from the qkv buffer, segment f writing its slice of
+        # y 'b s f (h d)'; the [B*h, N, N] logits, their softmax and the attn @ v product never exist
         lf = None if log_flat is None else log_flat.float().contiguous()
-        for f in range(F):
-            sl = slice(1 + f * P, 1 + (f + 1) * P)
-            _abi.prop_attention(heads[0][:, :, 1:], heads[1][:, :, sl], heads[2][:, :, sl], None, self.scale,
-                                log_bias=None if lf is None else lf[:, f * P:(f + 1) * P],
-                                out=y[:, :, f].view(B, N - 1, h, hd))
+        y = _abi.prop_attention_segments(heads[0][:, :, 1:], heads[1][:, :, 1:1 + P * F], heads[2][:, :, 1:1 + P * F], F,
+                                         self.scale, log_bias=lf)
     else:
+        q, k, v = (rearrange(t, "b n (h d) -> (b h) n d", h=h) for t in qkv.chunk(3, dim=-1))
+        (cls_q, q_), (cls_k, k_), (cls_v, v_) = ((t[:, 0:1], t[:, 1:]) for t in (q, k, v))
+        cls_out = rearrange(qkv_attn(cls_q * self.scale, k, v), "(b h) f d -> b f (h d)", f=1, h=h)
         q_dot_k = rearrange(q_ @ k_.transpose(-2, -1), "b q (f n) -> b q f n", f=F) * self.scale
         if log_flat is not None:
             q_dot_k = rearrange(q_dot_k, "(b h) q f n -> b h q (f n)", h=h, f=F)
@@ -94,8 +94,11 @@ def _trajectory_forward(self, x, seq_len=196, num_frames=8, approx="none", num_l
         val = rearrange(val_tok, "b s f (h d) -> b h s f d", f=F, h=h)
         out = rearrange((val * tattn.unsqueeze(-1)).sum(dim=-2), "b h s d -> b s (h d)")  # same remark
     out = self.proj_drop(self.proj(torch.cat((cls_out, out), dim=1)))
-    keys = rearrange(k_, "(b h) (s f) d -> (b f) h s d", f=F, h=h)
-    return out, tattn, keys.mean(1)
+    # metric = rearrange(k_, '(b h) (s f) d -> (b f) h s d').mean(1) (motionformer.py:143-144): the regrouped keys
+    # are a strided view of the qkv buffer -- [b, f, h, s, d] with token 1 + s*F + f -- and the head mean is taken
+    # inside the matching kernel (tome_match_keys with inner groups), never as a tensor
+    kview = heads[1][:, :, 1:1 + P * F, :].unflatten(2, (P, F)).permute(0, 3, 1, 2, 4)
+    return out, tattn, HeadMeanKeys(kview)
 
 
 def _regroup(x, num_frames):

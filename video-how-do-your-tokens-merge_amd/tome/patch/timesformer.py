@@ -6,6 +6,7 @@ from __future__ import annotations
 import torch
 
 from . import _common as C
+from .. import _abi
 from ..merge import HeadMeanKeys
 
 
@@ -24,23 +25,31 @@ def _block_forward(self, x, B, T, W):
     xn = C.first_norm(self, x, info, self.temporal_norm1)
     rt = self.drop_path(self.temporal_attn(xn[:, 1:, :].reshape(B * P, T, m))).reshape(B, P * T, m)
     cls0 = x[:, :1, :]
-    if torch.is_grad_enabled() and x.requires_grad:
-        # the reference's op sequence (differentiable): add, transpose, three cats
-        xt = x[:, 1:, :] + self.temporal_fc(rt)
-        x1 = torch.cat((cls0, xt), 1)
-        xs_in = torch.cat((cls0.expand(B, T, m).reshape(B * T, 1, m),
-                           xt.reshape(B, P, T, m).transpose(1, 2).reshape(B * T, P, m)), 1)
+    rt = self.temporal_fc(rt)
+    if C._FUSE_NEXT and rt.dtype == x.dtype and _abi.ln_fusable(x, self.norm1):
+        # residual of the temporal attention, 'b (p t) -> (b t) p' with the class token in front of every frame,
+        # and the spatial attention's norm1 -- one pass (tome_add_layernorm_regrouped); the regrouped
+        # un-normalised tokens never exist
+        x1, xs_normed = _abi.add_layernorm_regrouped(x, rt, T, self.norm1.weight, self.norm1.bias, self.norm1.eps)
     else:
-        # same values without the cat passes: the sum is written straight behind the class token, and
-        # 'b (p t) -> (b t) p' is ONE strided copy into the buffer that already holds the replicated class tokens
-        x1 = torch.empty_like(x)
-        x1[:, :1, :] = cls0
-        xt = torch.add(x[:, 1:, :], self.temporal_fc(rt), out=x1[:, 1:, :])
-        xs_in = torch.empty((B * T, 1 + P, m), dtype=x.dtype, device=x.device)
-        xs_in[:, 0, :] = cls0.expand(B, T, m).reshape(B * T, m)
-        xs_in.view(B, T, 1 + P, m)[:, :, 1:, :].copy_(xt.reshape(B, P, T, m).transpose(1, 2))
+        if torch.is_grad_enabled() and x.requires_grad:
+            # the reference's op sequence (differentiable): add, transpose, three cats
+            xt = x[:, 1:, :] + rt
+            x1 = torch.cat((cls0, xt), 1)
+            xs_in = torch.cat((cls0.expand(B, T, m).reshape(B * T, 1, m),
+                               xt.reshape(B, P, T, m).transpose(1, 2).reshape(B * T, P, m)), 1)
+        else:
+            # same values without the cat passes: the sum is written straight behind the class token, and
+            # 'b (p t) -> (b t) p' is ONE strided copy into the buffer that already holds the replicated class tokens
+            x1 = torch.empty_like(x)
+            x1[:, :1, :] = cls0
+            xt = torch.add(x[:, 1:, :], rt, out=x1[:, 1:, :])
+            xs_in = torch.empty((B * T, 1 + P, m), dtype=x.dtype, device=x.device)
+            xs_in[:, 0, :] = cls0.expand(B, T, m).reshape(B * T, m)
+            xs_in.view(B, T, 1 + P, m)[:, :, 1:, :].copy_(xt.reshape(B, P, T, m).transpose(1, 2))
+        xs_normed = self.norm1(xs_in)
     # spatial attention per frame, class token replicated into every frame
-    rs, metric = self.attn(self.norm1(xs_in), attn_size)
+    rs, metric = self.attn(xs_normed, attn_size)
     rs = self.drop_path(rs)
     cls_new = rs[:, 0, :].reshape(B, T, m).mean(1, keepdim=True)  # class token averaged over frames
     rs_body = rs.reshape(B, T, 1 + P, m)[:, :, 1:, :].transpose(1, 2)  # '(b t) p -> b p t', still a view
