@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""tome_prop_attention in isolation (HIP events, random bf16 q/k/v as strided views of one qkv buffer) next to
+PyTorch-ROCm's fused attention, plain and with the per-key log(size) bias.
+    python tools/attn_bench.py [--quick]"""
+import os
+import sys
+
+ROOT = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "video-how-do-your-tokens-merge_amd")]
+import torch  # noqa: E402
+import torch.nn.functional as F  # noqa: E402
+
+from tome import _abi  # noqa: E402
+
+dev = torch.device("cuda", 0)
+
+
+def timeit(f, n=20):
+    for _ in range(5):
+        f()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        f()
+    e1.record()
+    e1.synchronize()
+    return e0.elapsed_time(e1) / n * 1e3
+
+
+torch.manual_seed(0)
+shapes = [(128, 12, 1568), (128, 12, 1472), (8, 12, 3137), (64, 12, 197), (8, 12, 1568)]
+if "--quick" in sys.argv:
+    shapes = shapes[:2]
+ours_only = "--ours" in sys.argv
+for (B, H, N) in shapes:
+    qkv = torch.randn(B, N, 3, H, 64, device=dev).bfloat16()
+    q, k, v = qkv.permute(2, 0, 3, 1, 4)
+    size = torch.randint(1, 9, (B, N, 1), device=dev).float()
+    bias = size.log()[:, None, None, :, 0].bfloat16()
+    fl = 4.0 * B * H * N * N * 64
+    with torch.no_grad():
+        t0 = t1 = float("nan")
+        if not ours_only:
+            t0 = timeit(lambda: F.scaled_dot_product_attention(q, k, v, scale=0.125))
+            t1 = timeit(lambda: F.scaled_dot_product_attention(q, k, v, attn_mask=bias, scale=0.125))
+        t2 = timeit(lambda: _abi.prop_attention(q, k, v, None, 0.125))
+        t3 = timeit(lambda: _abi.prop_attention(q, k, v, size, 0.125))
+    print(f"{(B, H, N)}: sdpa {t0:7.1f} us ({fl / t0 / 1e6:5.0f} TF/s) | sdpa+bias {t1:7.1f} ({fl / t1 / 1e6:5.0f}) | "
+          f"ours {t2:7.1f} ({fl / t2 / 1e6:5.0f}) | ours+bias {t3:7.1f} ({fl / t3 / 1e6:5.0f})", flush=True)

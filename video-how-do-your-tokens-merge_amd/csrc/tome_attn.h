@@ -42,7 +42,6 @@
 #define ATT_D 64        // head dim
 #define ATT_BN 64       // keys per tile
 #define ATT_KS 72       // K tile row stride in elements (144 B: conflict-free ds_read_b128 over 16 rows)
-#define ATT_DEFER 6.0f  // log2 units: weights up to 64 before the running maximum is moved
 #define ATT_VS 96       // V tile row stride in elements (192 B: conflict-free ds_read_b64_tr_b16 over 4 rows)
 
 typedef float att_f32x16 __attribute__((ext_vector_type(16)));
@@ -87,6 +86,22 @@ template <> struct AttMfma<f16_t> {
     }
 };
 
+// Largest lane sum of un-normalised weights the plain path accepts before it moves the reference point: the weights
+// go to the second product in the 16-bit format (fp16 tops out at 65504; bf16 has fp32's range) and O / l
+// accumulate N of them in fp32.
+template <typename TX> struct AttLimit;
+template <> struct AttLimit<bf16_t> { static constexpr float value = 1.152921504606847e18f; };  // 2^60
+template <> struct AttLimit<f16_t> { static constexpr float value = 32768.0f; };                // 2^15
+
+__device__ __forceinline__ float att_add(float x, float y) {
+    // one v_add_f32 that the vectoriser cannot pair into v_pk_add_f32: the sum passes through an empty asm statement
+    // (the add itself stays a compiler instruction, so its hazards -- a transcendental result read by the next
+    // VALU instruction -- are padded by hipcc, which it would not do inside an asm string)
+    float r = x + y;
+    asm("" : "+v"(r));
+    return r;
+}
+
 template <typename TX> __device__ __forceinline__ short att_bits(float f) {
     const TX t = from_f32<TX>(f);
     short s;
@@ -122,24 +137,39 @@ __global__ __launch_bounds__(64 * WAVES) void k_prop_attention(AttnArgs a) {
     // this lane's query and its Q fragment: B operand of S^T = K Q^T (k = channel): 4 steps x 8 channels
     const int qrow = qb * ATT_BM + wave * 32 + col;
     const int qload = qrow < a.N ? qrow : a.N - 1;
-    att_s16x8 qf[4];
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks)
-        qf[ks] = *reinterpret_cast<const att_s16x8 *>(qp + (int64_t)qload * a.q_sn + 16 * ks + 8 * hf);
-    const bool unbiased_query = a.bias_skip && qrow == 0;
-    const float *bias_row = unbiased_query ? lds_mask : lds_bias;
-
+    // The fragment holds q * scale * log2(e) rounded ONCE to the 16-bit format (the reference rounds `q * self.scale`
+    // to it as well, tome/patch/videomae.py:58): the MFMA then delivers the logits in base-2 units and the softmax
+    // needs no multiply per score.
     const float LOG2E = 1.4426950408889634f;
     const float sl = a.scale * LOG2E;
+    att_s16x8 qf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        const att_s16x8 raw = *reinterpret_cast<const att_s16x8 *>(qp + (int64_t)qload * a.q_sn + 16 * ks + 8 * hf);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            TX t;
+            const short r = raw[e];
+            __builtin_memcpy(&t, &r, 2);
+            qf[ks][e] = att_bits<TX>(to_f32(t) * sl);
+        }
+    }
+    const bool active = qb * ATT_BM + wave * 32 < a.N;  // wave-uniform: does this wave own any query at all?
+    const bool unbiased_query = a.bias_skip && qrow == 0;
+    const float *bias_row = unbiased_query ? lds_mask : lds_bias;
     att_f32x16 o0, o1;
 #pragma unroll
     for (int v = 0; v < 16; ++v) o0[v] = o1[v] = 0.0f;
     float m_run = -INFINITY, l_run = 0.0f;
+    att_f32x16 negm;  // plain attention: -m_run in every register, the C operand the score MFMAs start from
+#pragma unroll
+    for (int v = 0; v < 16; ++v) negm[v] = 0.0f;
 
     const int ntiles = (a.Nk + ATT_BN - 1) / ATT_BN;
     // staging: thread t moves chunks c = t and t + 256 (16 B each) of the 64 x 64 K and V tiles
-    constexpr int NST = 512 / (64 * WAVES);  // 16-byte chunks of each tile per thread (2 with 4 waves, 1 with 8)
     constexpr int RSTEP = 8 * WAVES;         // rows covered by one pass of the workgroup
+    constexpr int NST = (ATT_BN + RSTEP - 1) / RSTEP;  // passes: 16-byte chunks of each tile per thread (1 with 8 waves)
+    constexpr bool EVEN = (ATT_BN % RSTEP) == 0;       // 5, 6, 7 waves: the last pass covers fewer rows
     const int r0 = tid >> 3, c0 = tid & 7;   // rows r0 (+ RSTEP), 16-byte column c0
     uint4 kreg[NST], vreg[NST];
     float breg = 0.0f, mreg = 0.0f;
@@ -148,6 +178,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_prop_attention(AttnArgs a) {
 #pragma unroll
         for (int i = 0; i < NST; ++i) {
             const int key = key0 + r0 + RSTEP * i;
+            if (!EVEN && r0 + RSTEP * i >= ATT_BN) continue;
             if (key < a.Nk) {
                 kreg[i] = *reinterpret_cast<const uint4 *>(kp + (int64_t)key * a.k_sn + 8 * c0);
                 vreg[i] = *reinterpret_cast<const uint4 *>(vp + (int64_t)key * a.v_sn + 8 * c0);
@@ -168,6 +199,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_prop_attention(AttnArgs a) {
     auto stage_write = [&]() {
 #pragma unroll
         for (int i = 0; i < NST; ++i) {
+            if (!EVEN && r0 + RSTEP * i >= ATT_BN) continue;
             *reinterpret_cast<uint4 *>(lds_k + (r0 + RSTEP * i) * ATT_KS + 8 * c0) = kreg[i];
             *reinterpret_cast<uint4 *>(lds_v + (r0 + RSTEP * i) * ATT_VS + 8 * c0) = vreg[i];
         }
@@ -184,24 +216,13 @@ __global__ __launch_bounds__(64 * WAVES) void k_prop_attention(AttnArgs a) {
     for (int t = 0; t < ntiles; ++t) {
         if (t + 1 < ntiles) stage_load(t + 1);
 
-        // ---- S^T = K Q^T : two blocks of 32 keys, four channel steps
-        att_f32x16 s0, s1;
-#pragma unroll
-        for (int v = 0; v < 16; ++v) s0[v] = s1[v] = 0.0f;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            const att_s16x8 k0 = *reinterpret_cast<const att_s16x8 *>(lds_k + col * ATT_KS + 16 * ks + 8 * hf);
-            const att_s16x8 k1 = *reinterpret_cast<const att_s16x8 *>(lds_k + (32 + col) * ATT_KS + 16 * ks + 8 * hf);
-            s0 = AttMfma<TX>::run(k0, qf[ks], s0);
-            s1 = AttMfma<TX>::run(k1, qf[ks], s1);
-        }
-        // ---- V^T fragments of the whole tile, requested now so that their LDS latency passes under the softmax:
-        //      channel row = col (+32), one transposed read delivers 4 consecutive keys of one channel: lane
-        //      i = 4*rq + pc of a 16-lane group addresses row rq, columns 4*pc .. 4*pc+3 of a 4 x 16 block and
-        //      receives column i.  Step (kb, p) contracts key slots {8*hf' + e} = keys 32*kb + 16*p + 8*(e>>2) +
-        //      4*hf' + (e&3): the keys a lane holds in registers 8p .. 8p+7 of its score block kb.
+        // ---- V^T fragments of the whole tile are requested first so that their LDS latency passes under the scores
+        //      and the softmax: channel row = col (+32), one transposed read delivers 4 consecutive keys of one
+        //      channel: lane i = 4*rq + pc of a 16-lane group addresses row rq, columns 4*pc .. 4*pc+3 of a 4 x 16
+        //      block and receives column i.  Step (kb, p) contracts key slots {8*hf' + e} = keys 32*kb + 16*p +
+        //      8*(e>>2) + 4*hf' + (e&3): the keys a lane holds in registers 8p .. 8p+7 of its score block kb.
         att_s16x4 vfr[2][2][4];
-        {
+        auto v_fragments = [&]() {
             typedef __attribute__((address_space(3))) att_s16x4 *lds_s16x4_p;
             const int grp = (lane >> 4) & 1, li = lane & 15, rq = li >> 2, pc = li & 3;
 #pragma unroll
@@ -214,62 +235,68 @@ __global__ __launch_bounds__(64 * WAVES) void k_prop_attention(AttnArgs a) {
                     vfr[kb][p][2] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(va + 32));
                     vfr[kb][p][3] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(va + 8 * ATT_VS + 32));
                 }
-        }
-        // Plain attention (BIAS = false, scale > 0), every key of the tile in range, not the first tile: the
-        // weights are taken against the CURRENT reference point m_run without waiting for this tile's maximum --
-        // exp2(s*sl - m_run) is one fma + one exp per score, issued as the MFMA results arrive; the maximum is
-        // reduced beside them and only checked afterwards.  While no query's maximum grew by more than 2^ATT_DEFER
-        // the weights (<= 2^ATT_DEFER instead of <= 1) are used as they are: O and l carry the same factor, the
-        // result is exact.  Otherwise (rare after the first tiles) the reference moves and the tile is redone.
-        const bool speculative = !BIAS && t > 0 && (t + 1) * ATT_BN <= a.Nk;
-        if (speculative) {
-            const float nm = -m_run;
-            float mx = -INFINITY, lsum = 0.0f;
-            att_f32x16 t0, t1;
+        };
+        // ---- S^T = K Q~^T (+ c0): two blocks of 32 keys, four channel steps; logits in base-2 units
+        att_f32x16 s0, s1;
+        auto scores = [&](const att_f32x16 &c0) {
+            s0 = c0;
+            s1 = c0;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const att_s16x8 k0 = *reinterpret_cast<const att_s16x8 *>(lds_k + col * ATT_KS + 16 * ks + 8 * hf);
+                const att_s16x8 k1 = *reinterpret_cast<const att_s16x8 *>(lds_k + (32 + col) * ATT_KS + 16 * ks + 8 * hf);
+                s0 = AttMfma<TX>::run(k0, qf[ks], s0);
+                s1 = AttMfma<TX>::run(k1, qf[ks], s1);
+            }
+        };
+        // Plain attention (BIAS = false), every key of the tile in range, not the first tile: the accumulators START
+        // at -m_run (the register block `negm`, rewritten only when the reference point moves), so the matrix pipe
+        // delivers s - m_run and a weight is ONE v_exp_f32 -- no scale, no subtraction, no maximum.  The weights are
+        // taken against the current reference point whatever this tile's maximum is: O and l carry the same factor,
+        // the result is exact as long as nothing overflows -- which the row sum that is needed anyway tells: a lane
+        // sum above ATT_LIMIT (or inf / NaN) sends the whole wave through the general path below, which recomputes
+        // the tile's scores from LDS and moves the reference (first tiles and adversarial inputs only).
+        bool general = BIAS || t == 0 || (t + 1) * ATT_BN > a.Nk;
+        float lsum = 0.0f;
+        if (!active) {
+            general = false;  // a wave past the last query only helps staging the tiles
+        } else if (!general) {
+            scores(negm);
+            v_fragments();
 #pragma unroll
             for (int v = 0; v < 16; ++v) {
-                t0[v] = __builtin_fmaf(s0[v], sl, nm);
-                t1[v] = __builtin_fmaf(s1[v], sl, nm);
-                s0[v] = __builtin_amdgcn_exp2f(t0[v]);
-                s1[v] = __builtin_amdgcn_exp2f(t1[v]);
-                mx = fmaxf(mx, fmaxf(t0[v], t1[v]));
+                s0[v] = __builtin_amdgcn_exp2f(s0[v]);
+                s1[v] = __builtin_amdgcn_exp2f(s1[v]);
             }
-            {
-                const unsigned mb = __float_as_uint(mx);
-                const auto sw = __builtin_amdgcn_permlane32_swap(mb, mb, false, false);
-                mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
-            }
-            if (!__all(mx <= ATT_DEFER)) {
-                const float grow = fmaxf(mx, 0.0f);  // this query's reference moves up by `grow` (0: stays)
-                const float alpha = __builtin_amdgcn_exp2f(-grow);
+            {   // row sum as single f32 adds in four chains (packed v_pk_add_f32 costs more beside MFMAs than two adds)
+                float c0 = att_add(s0[0], s1[0]), c1 = att_add(s0[1], s1[1]), c2 = att_add(s0[2], s1[2]),
+                      c3 = att_add(s0[3], s1[3]);
 #pragma unroll
-                for (int v = 0; v < 16; ++v) {
-                    s0[v] = __builtin_amdgcn_exp2f(t0[v] - grow);
-                    s1[v] = __builtin_amdgcn_exp2f(t1[v] - grow);
-                    o0[v] *= alpha;
-                    o1[v] *= alpha;
+                for (int v = 4; v < 16; v += 4) {
+                    c0 = att_add(c0, s0[v]);     c1 = att_add(c1, s0[v + 1]);
+                    c2 = att_add(c2, s0[v + 2]); c3 = att_add(c3, s0[v + 3]);
+                    c0 = att_add(c0, s1[v]);     c1 = att_add(c1, s1[v + 1]);
+                    c2 = att_add(c2, s1[v + 2]); c3 = att_add(c3, s1[v + 3]);
                 }
-                l_run *= alpha;
-                m_run += grow;
+                lsum = att_add(att_add(c0, c1), att_add(c2, c3));
             }
+            general = !__all(lsum <= AttLimit<TX>::value);
+            if (!general) l_run += lsum;
+        }
+        if (general) {
+            att_f32x16 zero;
 #pragma unroll
-            for (int v = 0; v < 16; ++v) lsum += s0[v] + s1[v];
-            l_run += lsum;
-        } else {
-        // ---- logits in base 2 with the per-key bias; register v <-> key (v&3) + 8*(v>>2) + 4*hf (+32)
+            for (int v = 0; v < 16; ++v) zero[v] = 0.0f;
+            scores(zero);
+            v_fragments();
+            // ---- logits with the per-key bias (or the range mask); register v <-> key (v&3) + 8*(v>>2) + 4*hf (+32)
             float mt = -INFINITY;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const float4 b0 = *reinterpret_cast<const float4 *>(bias_row + 8 * g + 4 * hf);
                 const float4 b1 = *reinterpret_cast<const float4 *>(bias_row + 32 + 8 * g + 4 * hf);
-                s0[4 * g + 0] = __builtin_fmaf(s0[4 * g + 0], sl, b0.x);
-                s0[4 * g + 1] = __builtin_fmaf(s0[4 * g + 1], sl, b0.y);
-                s0[4 * g + 2] = __builtin_fmaf(s0[4 * g + 2], sl, b0.z);
-                s0[4 * g + 3] = __builtin_fmaf(s0[4 * g + 3], sl, b0.w);
-                s1[4 * g + 0] = __builtin_fmaf(s1[4 * g + 0], sl, b1.x);
-                s1[4 * g + 1] = __builtin_fmaf(s1[4 * g + 1], sl, b1.y);
-                s1[4 * g + 2] = __builtin_fmaf(s1[4 * g + 2], sl, b1.z);
-                s1[4 * g + 3] = __builtin_fmaf(s1[4 * g + 3], sl, b1.w);
+                s0[4 * g + 0] += b0.x; s0[4 * g + 1] += b0.y; s0[4 * g + 2] += b0.z; s0[4 * g + 3] += b0.w;
+                s1[4 * g + 0] += b1.x; s1[4 * g + 1] += b1.y; s1[4 * g + 2] += b1.z; s1[4 * g + 3] += b1.w;
             }
 #pragma unroll
             for (int v = 0; v < 16; ++v) mt = fmaxf(mt, fmaxf(s0[v], s1[v]));
@@ -281,7 +308,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_prop_attention(AttnArgs a) {
             }
             const float m_new = fmaxf(m_run, mt);  // finite: every tile holds at least one key in range
             const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-            float lsum = 0.0f;
+            lsum = 0.0f;
 #pragma unroll
             for (int v = 0; v < 16; ++v) {
                 s0[v] = __builtin_amdgcn_exp2f(s0[v] - m_new);
@@ -295,8 +322,14 @@ __global__ __launch_bounds__(64 * WAVES) void k_prop_attention(AttnArgs a) {
                 o0[v] *= alpha;
                 o1[v] *= alpha;
             }
+            if (!BIAS) {
+#pragma unroll
+                for (int v = 0; v < 16; ++v) negm[v] = -m_new;
+                asm volatile("" : "+v"(negm));  // a register block of its own, not a splat re-made per tile
+            }
         }
         // ---- O^T += V^T P^T
+        if (active) {
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
@@ -314,6 +347,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_prop_attention(AttnArgs a) {
                 o0 = AttMfma<TX>::run(vf0, pf, o0);
                 o1 = AttMfma<TX>::run(vf1, pf, o1);
             }
+        }
         }
         __syncthreads();  // every wave is done with tile t
         if (t + 1 < ntiles) stage_write();

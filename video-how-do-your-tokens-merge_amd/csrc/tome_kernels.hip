@@ -755,7 +755,9 @@ static int prop_attention_impl(const void *q, const void *k, const void *v, int 
             return fail(TOME_EINVAL, "tome_prop_attention_segments: segment offsets must keep rows 16/8-byte aligned");
         a.k_seg = seg_strides[0]; a.v_seg = seg_strides[1]; a.o_seg = seg_strides[2]; a.ls_seg = seg_strides[3];
     }
-    // queries per workgroup: 256 (eight waves share every staged K/V tile) unless the sequence is short
+    // queries per workgroup: 256 (eight waves share every staged K/V tile: staging costs 18 % with four) unless the
+    // sequence is short.  (Measured: 5, 6 or 7 waves per workgroup, chosen to leave no part-empty last block, are
+    // 10-30 % slower per block than eight -- uneven staging passes and SIMD load -- and lose more than they save.)
     static const int waves_env = [] {
         const char *e = getenv("TOME_ATTN_WAVES");
         int v = e ? atoi(e) : 0;
@@ -767,16 +769,16 @@ static int prop_attention_impl(const void *q, const void *k, const void *v, int 
     if (bh8 * qblocks > 0x7fffffffLL) return fail(TOME_EINVAL, "tome_prop_attention: grid too large");
     const dim3 grid((unsigned)(bh8 * qblocks));
     hipStream_t st = (hipStream_t)stream;
-    static const bool spec_env = [] { const char *e = getenv("TOME_ATTN_SPEC"); return !(e && atoi(e) == 0); }();
-    const bool plain = spec_env && !log_size && scale > 0.0f;  // no per-key term: the speculative softmax (tome_attn.h)
+    const bool plain = !log_size;  // no per-key term: the accumulator-start softmax (tome_attn.h)
 #define ATT_LAUNCH(TX, W, BI) hipLaunchKernelGGL((k_prop_attention<TX, W, BI>), grid, dim3(64 * W), 0, st, a)
+#define ATT_WAVES(TX, BI) \
+    if (waves == 8) ATT_LAUNCH(TX, 8, BI); else ATT_LAUNCH(TX, 4, BI);
     if (dtype == TOME_BF16) {
-        if (waves == 8) { if (plain) ATT_LAUNCH(bf16_t, 8, false); else ATT_LAUNCH(bf16_t, 8, true); }
-        else { if (plain) ATT_LAUNCH(bf16_t, 4, false); else ATT_LAUNCH(bf16_t, 4, true); }
+        if (plain) { ATT_WAVES(bf16_t, false) } else { ATT_WAVES(bf16_t, true) }
     } else {
-        if (waves == 8) { if (plain) ATT_LAUNCH(f16_t, 8, false); else ATT_LAUNCH(f16_t, 8, true); }
-        else { if (plain) ATT_LAUNCH(f16_t, 4, false); else ATT_LAUNCH(f16_t, 4, true); }
+        if (plain) { ATT_WAVES(f16_t, false) } else { ATT_WAVES(f16_t, true) }
     }
+#undef ATT_WAVES
 #undef ATT_LAUNCH
     return check_launch("k_prop_attention");
 }
