@@ -374,6 +374,414 @@ __global__ __launch_bounds__(64 * WAVES) void k_prop_attention(AttnArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_attention_plain: softmax(q k^T * scale) v without a per-key term (VideoMAE's default, prop_attn = False --
+// tome/patch/videomae.py:55-66 with size None; every patched attention before the first merge; the class token of
+// Motionformer), software-pipelined over the key tiles:
+//
+//   iteration t:   S(t+1) = K(t+1) Q~^T - m_run     8 MFMAs   (score accumulators start at the block `negm`)
+//                  O     += V(t)^T P(t)^T            8 MFMAs
+//                  P(t+1) = exp2(S(t+1)), row sum, conversion to the 16-bit format    ~80 vector instructions
+//
+// The matrix work of an iteration does not depend on its vector work (P(t) was finished one iteration earlier), so
+// the two interleave inside every wave -- the matrix pipe runs while the softmax issues -- instead of alternating
+// between a matrix phase and a softmax phase that all waves of a workgroup enter together.  K/V tiles go through a
+// three-slot LDS ring (tile t+1 is written while slow waves may still read V(t) and K(t+1)): one barrier per tile.
+// First tile, a partly filled last tile, and a tile whose row sum trips the overflow guard take the general path
+// (scores recomputed from zero, maximum, rescale of O and l) behind a wave-uniform branch.
+// ------------------------------------------------------------------------------------------------
+#define ATT_SLOTS 2
+#ifndef ATT_ABL
+#define ATT_ABL 0  // measurement builds only (tools/ab_lib.sh): bit 0 no v_exp, 1 no barrier, 2 no V-fragment reads,
+#endif             // 3 no LDS staging writes, 4 no global loads in the fast step -- results are wrong by design
+#ifndef ATT_VARIANT
+#define ATT_VARIANT 0  // 0: the compiler orders the fast step; 1: hand-placed order behind scheduling fences
+#endif
+
+template <int V> struct AttInt { static constexpr int value = V; };
+
+template <typename TX, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void k_attention_plain(AttnArgs a) {
+    constexpr int ATT_BM = 32 * WAVES;
+    // two LDS slots: tile t lives in slot t & 1.  Tile t+1 is written during iteration t, when every wave has left
+    // iteration t-2 -- the last one that read slot (t+1) & 1 (K(t-1) for its scores, V(t-1) into registers).
+    __shared__ __attribute__((aligned(16))) short lds_k[ATT_SLOTS][ATT_BN * ATT_KS];
+    __shared__ __attribute__((aligned(16))) short lds_v[ATT_SLOTS][ATT_BN * ATT_VS];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int col = lane & 31, hf = lane >> 5;
+    const int qblocks = (a.N + ATT_BM - 1) / ATT_BM;
+    const int L = blockIdx.x;
+    const int xcd = L & 7, sq = L >> 3;
+    const int bhs = (sq / qblocks) * 8 + xcd;
+    if (bhs >= a.B * a.H * a.nseg) return;
+    const int qb = sq % qblocks;
+    const int bh = bhs / a.nseg, seg = bhs - bh * a.nseg;
+    const int b = bh / a.H, h = bh % a.H;
+    const short *qp = reinterpret_cast<const short *>(a.q) + b * a.q_sb + h * a.q_sh;
+    const short *kp = reinterpret_cast<const short *>(a.k) + b * a.k_sb + h * a.k_sh + seg * a.k_seg;
+    const short *vp = reinterpret_cast<const short *>(a.v) + b * a.v_sb + h * a.v_sh + seg * a.v_seg;
+
+    const int qrow = qb * ATT_BM + wave * 32 + col;
+    const int qload = qrow < a.N ? qrow : a.N - 1;
+    const bool active = qb * ATT_BM + __builtin_amdgcn_readfirstlane(wave) * 32 < a.N;  // wave-uniform (scalar)
+    const float sl = a.scale * 1.4426950408889634f;
+    att_s16x8 qf[4];  // q * scale * log2(e), rounded once to the 16-bit format (see k_prop_attention)
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        const att_s16x8 raw = *reinterpret_cast<const att_s16x8 *>(qp + (int64_t)qload * a.q_sn + 16 * ks + 8 * hf);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            TX tq;
+            const short r = raw[e];
+            __builtin_memcpy(&tq, &r, 2);
+            qf[ks][e] = att_bits<TX>(to_f32(tq) * sl);
+        }
+    }
+
+    att_f32x16 o0, o1, negm;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) o0[v] = o1[v] = negm[v] = 0.0f;
+    float m_run = -INFINITY, l_run = 0.0f;
+    const int ntiles = (a.Nk + ATT_BN - 1) / ATT_BN;
+    const int nfull = a.Nk / ATT_BN;  // tiles 0 .. nfull-1 hold 64 keys
+
+    // staging through registers: thread -> rows r0 (+ RSTEP), 16-byte column c0 of the 64 x 64 K and V tiles
+    constexpr int RSTEP = 8 * WAVES;
+    constexpr int NST = ATT_BN / RSTEP;  // WAVES is 4 or 8
+    const int r0 = tid >> 3, c0 = tid & 7;
+    uint4 kreg[NST], vreg[NST];
+    auto stage_load = [&](int t) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < NST; ++i) {
+            const int key = t * ATT_BN + r0 + RSTEP * i;
+            if (key < a.Nk) {
+                kreg[i] = *reinterpret_cast<const uint4 *>(kp + (int64_t)key * a.k_sn + 8 * c0);
+                vreg[i] = *reinterpret_cast<const uint4 *>(vp + (int64_t)key * a.v_sn + 8 * c0);
+            } else {
+                kreg[i] = uint4{0, 0, 0, 0};
+                vreg[i] = uint4{0, 0, 0, 0};  // zeros: weight 0 times a finite value
+            }
+        }
+    };
+    // (the lambdas below take the LDS slot as a plain int: inlined with a literal it folds into the instructions'
+    // immediate offsets -- the fast loop; with a run-time value it costs an address add -- the general path)
+    short *const wk = &lds_k[0][0] + r0 * ATT_KS + 8 * c0, *const wv = &lds_v[0][0] + r0 * ATT_VS + 8 * c0;
+    auto stage_write = [&](int S) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < NST; ++i) {
+            *reinterpret_cast<uint4 *>(wk + S * ATT_BN * ATT_KS + RSTEP * i * ATT_KS) = kreg[i];
+            *reinterpret_cast<uint4 *>(wv + S * ATT_BN * ATT_VS + RSTEP * i * ATT_VS) = vreg[i];
+        }
+    };
+    // V^T fragments of a whole tile (layout: k_prop_attention); lane-constant base
+    typedef __attribute__((address_space(3))) att_s16x4 *lds_s16x4_p;
+    const short *const vbase = &lds_v[0][0] + (4 * hf + ((lane & 15) >> 2)) * ATT_VS + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+    att_s16x4 vfr[2][2][4];
+    auto v_fragments = [&](int S) __attribute__((always_inline)) {
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const short *va = vbase + S * ATT_BN * ATT_VS + (32 * kb + 16 * p) * ATT_VS;
+                vfr[kb][p][0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(va));
+                vfr[kb][p][1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(va + 8 * ATT_VS));
+                vfr[kb][p][2] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(va + 32));
+                vfr[kb][p][3] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(va + 8 * ATT_VS + 32));
+            }
+    };
+    const short *const kbase = &lds_k[0][0] + col * ATT_KS + 8 * hf;
+    att_f32x16 s0, s1;
+    auto scores = [&](int S, const att_f32x16 &cinit) __attribute__((always_inline)) {
+        // block 0 (keys 0..31) completes before block 1 starts: its weights can be taken while block 1 multiplies
+        s0 = cinit;
+        s1 = cinit;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+            s0 = AttMfma<TX>::run(*reinterpret_cast<const att_s16x8 *>(kbase + S * ATT_BN * ATT_KS + 16 * ks), qf[ks], s0);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+            s1 = AttMfma<TX>::run(*reinterpret_cast<const att_s16x8 *>(kbase + S * ATT_BN * ATT_KS + 32 * ATT_KS + 16 * ks),
+                                  qf[ks], s1);
+    };
+    // P (fp32 weights in s0, s1) -> the four 16-bit B fragments of O^T += V^T P^T
+    att_s16x8 pf[2][2];
+    auto pack_p = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                pf[0][p][e] = att_bits<TX>(s0[8 * p + e]);
+                pf[1][p][e] = att_bits<TX>(s1[8 * p + e]);
+            }
+    };
+    // general softmax of tile t from scores that start at zero: range mask, maximum, rescale of O and l
+    auto general_softmax = [&](int t, int S) __attribute__((always_inline)) {
+        att_f32x16 zero;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) zero[v] = 0.0f;
+        scores(S, zero);
+        const int key0 = t * ATT_BN + 4 * hf;
+        float mt = -INFINITY;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            const int key = key0 + (v & 3) + 8 * (v >> 2);
+            s0[v] = key < a.Nk ? s0[v] : -INFINITY;
+            s1[v] = key + 32 < a.Nk ? s1[v] : -INFINITY;
+            mt = fmaxf(mt, fmaxf(s0[v], s1[v]));
+        }
+        {
+            const unsigned mb = __float_as_uint(mt);
+            const auto sw = __builtin_amdgcn_permlane32_swap(mb, mb, false, false);
+            mt = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+        }
+        const float m_new = fmaxf(m_run, mt);  // finite: every tile holds at least one key in range
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        float lsum = 0.0f;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            s0[v] = __builtin_amdgcn_exp2f(s0[v] - m_new);
+            s1[v] = __builtin_amdgcn_exp2f(s1[v] - m_new);
+            lsum += s0[v] + s1[v];
+        }
+        l_run = l_run * alpha + lsum;
+        m_run = m_new;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            o0[v] *= alpha;
+            o1[v] *= alpha;
+            negm[v] = -m_new;
+        }
+        pack_p();
+    };
+    auto pv = [&]() __attribute__((always_inline)) {  // O^T += V(t)^T P(t)^T from the fragments in registers
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                att_s16x8 vf0, vf1;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    vf0[e] = vfr[kb][p][0][e];
+                    vf0[4 + e] = vfr[kb][p][1][e];
+                    vf1[e] = vfr[kb][p][2][e];
+                    vf1[4 + e] = vfr[kb][p][3][e];
+                }
+                o0 = AttMfma<TX>::run(vf0, pf[kb][p], o0);
+                o1 = AttMfma<TX>::run(vf1, pf[kb][p], o1);
+            }
+    };
+    // One iteration = tile t (weights and V fragments in registers) is accumulated while tile t+1 (slot S after the
+    // barrier) gets its scores and weights.
+    //   fast_step: tile t+1 holds 64 keys.  Straight-line code -- 16 MFMAs and ~80 vector instructions free to
+    //   interleave.  The overflow guard only sets a flag (see below).
+    bool bad = false;
+    att_s16x4 vfn[2][2][4];  // the V fragments of tile t+1 arrive here while the matrix pipe still reads vfr
+    auto fast_step = [&](int S, int t) __attribute__((always_inline)) {
+#if !(ATT_ABL & 8)
+        stage_write(S);  // registers hold tile t+1
+#endif
+        // tile t+2, rows clamped to the last key instead of a bounds branch (a partly filled tile gets its scores
+        // masked by the general softmax; its weights are 0, so a repeated V row adds nothing): no control flow
+        // between two barriers
+#pragma unroll
+        for (int i = 0; i < NST; ++i) {
+            const int key = min((t + 2) * ATT_BN + r0 + RSTEP * i, a.Nk - 1);
+#if !(ATT_ABL & 16)
+            kreg[i] = *reinterpret_cast<const uint4 *>(kp + (int64_t)key * a.k_sn + 8 * c0);
+            vreg[i] = *reinterpret_cast<const uint4 *>(vp + (int64_t)key * a.v_sn + 8 * c0);
+#endif
+        }
+#if !(ATT_ABL & 2)
+        __syncthreads();   // tile t+1 visible; every wave has left iteration t-1
+#endif
+#if ATT_VARIANT == 1
+        // Hand-placed issue order, pinned by scheduling fences: every MFMA is followed by the vector work that can
+        // run in its shadow, so the matrix pipe and the softmax overlap inside the wave.
+        //   block 0 of the scores (4 MFMAs)                        | K and next V fragments are fetched
+        //   block 1 of the scores (4 MFMAs), each + 4 v_exp_f32 of block 0
+        //   O += V P (8 MFMAs), each + 2 v_exp_f32 of block 1 + 4 row-sum additions + 2 conversions
+        att_s16x8 kf[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            kf[i] = *reinterpret_cast<const att_s16x8 *>(kbase + S * ATT_BN * ATT_KS + (i >> 2) * 32 * ATT_KS + 16 * (i & 3));
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const short *va = vbase + S * ATT_BN * ATT_VS + (32 * kb + 16 * p) * ATT_VS;
+                vfn[kb][p][0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(va));
+                vfn[kb][p][1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(va + 8 * ATT_VS));
+                vfn[kb][p][2] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(va + 32));
+                vfn[kb][p][3] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(va + 8 * ATT_VS + 32));
+            }
+        s0 = AttMfma<TX>::run(kf[0], qf[0], negm);
+        s0 = AttMfma<TX>::run(kf[1], qf[1], s0);
+        s0 = AttMfma<TX>::run(kf[2], qf[2], s0);
+        s0 = AttMfma<TX>::run(kf[3], qf[3], s0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            s1 = AttMfma<TX>::run(kf[4 + i], qf[i], i == 0 ? negm : s1);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s0[4 * i + e] = __builtin_amdgcn_exp2f(s0[4 * i + e]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        float cs[4];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int kb = j >> 2, p = (j >> 1) & 1, half = j & 1;
+            att_s16x8 vf;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                vf[e] = vfr[kb][p][2 * half][e];
+                vf[4 + e] = vfr[kb][p][2 * half + 1][e];
+            }
+            if (half == 0) o0 = AttMfma<TX>::run(vf, pf[kb][p], o0);
+            else o1 = AttMfma<TX>::run(vf, pf[kb][p], o1);
+            s1[2 * j] = __builtin_amdgcn_exp2f(s1[2 * j]);
+            s1[2 * j + 1] = __builtin_amdgcn_exp2f(s1[2 * j + 1]);
+            // row-sum additions whose operands are ready (four chains over register index mod 4)
+            if (j == 0) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) cs[k] = att_add(s0[k], s0[4 + k]);
+            } else if (j == 1 || j == 2) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) cs[k] = att_add(cs[k], s0[4 * (j + 1) + k]);
+            } else if (j >= 3 && j <= 5) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) cs[k] = att_add(cs[k], s1[4 * (j - 3) + k]);
+            } else if (j == 6) {
+                cs[0] = att_add(cs[0], s1[12]);
+                cs[1] = att_add(cs[1], s1[13]);
+            }
+            // conversions into the P fragments the matrix pipe has finished reading
+            if (j == 2 || j == 3) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) pf[0][0][4 * (j - 2) + e] = att_bits<TX>(s0[4 * (j - 2) + e]);
+            } else if (j == 4 || j == 5) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) pf[0][1][4 * (j - 4) + e] = att_bits<TX>(s0[8 + 4 * (j - 4) + e]);
+            } else if (j == 6 || j == 7) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) pf[1][0][4 * (j - 6) + e] = att_bits<TX>(s1[4 * (j - 6) + e]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        cs[2] = att_add(cs[2], s1[14]);
+        cs[3] = att_add(cs[3], s1[15]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) pf[1][1][e] = att_bits<TX>(s1[8 + e]);
+        const float lsum = att_add(att_add(cs[0], cs[1]), att_add(cs[2], cs[3]));
+        l_run += lsum;
+        bad = bad || !(lsum <= AttLimit<TX>::value);  // inf / NaN / too large: this pass is void (rerun below)
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) vfr[kb][p][q] = vfn[kb][p][q];
+#else
+        // compiler-scheduled form of the same work
+        scores(S, negm);
+        pv();
+#if !(ATT_ABL & 4)
+        v_fragments(S);
+#endif
+#if !(ATT_ABL & 1)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) s0[v] = __builtin_amdgcn_exp2f(s0[v]);
+#pragma unroll
+        for (int v = 0; v < 16; ++v) s1[v] = __builtin_amdgcn_exp2f(s1[v]);
+#endif
+        float c0s = att_add(s0[0], s0[4]), c1s = att_add(s0[1], s0[5]), c2s = att_add(s0[2], s0[6]),
+              c3s = att_add(s0[3], s0[7]);
+#pragma unroll
+        for (int v = 8; v < 16; v += 4) {
+            c0s = att_add(c0s, s0[v]);     c1s = att_add(c1s, s0[v + 1]);
+            c2s = att_add(c2s, s0[v + 2]); c3s = att_add(c3s, s0[v + 3]);
+        }
+#pragma unroll
+        for (int v = 0; v < 16; v += 4) {
+            c0s = att_add(c0s, s1[v]);     c1s = att_add(c1s, s1[v + 1]);
+            c2s = att_add(c2s, s1[v + 2]); c3s = att_add(c3s, s1[v + 3]);
+        }
+        const float lsum = att_add(att_add(c0s, c1s), att_add(c2s, c3s));
+        pack_p();
+        l_run += lsum;
+        bad = bad || !(lsum <= AttLimit<TX>::value);  // inf / NaN / too large: this pass is void (rerun below)
+#endif
+    };
+    //   slow_step: any tile t+1 (partly filled, or the general pass): general softmax, run-time slot.
+    auto slow_step = [&](int t) __attribute__((always_inline)) {
+        const int S = (t + 1) & 1;
+        stage_write(S);
+        if (t + 2 < ntiles) stage_load(t + 2);
+        __syncthreads();
+        pv();
+        v_fragments(S);
+        general_softmax(t + 1, S);  // (O already holds tile t: the rescale applies to all of it)
+    };
+    //   a wave that owns no query only stages and meets the barriers
+    auto helper_step = [&](int t) __attribute__((always_inline)) {
+        stage_write((t + 1) & 1);
+        if (t + 2 < ntiles) stage_load(t + 2);
+        __syncthreads();
+    };
+
+    // Pass 0 takes the fast form wherever a tile is full.  Should a row sum have tripped the guard in any wave of
+    // the workgroup (weights beyond the 16-bit format's range or an overflow: the running reference point lagged
+    // the scores by more than the format allows -- adversarial inputs), the workgroup repeats the block on the
+    // general path (pass 1), whose reference point follows the maximum tile by tile.
+    for (int pass = 0; pass < 2; ++pass) {
+        if (pass == 1) {
+            if (!__syncthreads_or(bad ? 1 : 0)) break;
+#pragma unroll
+            for (int v = 0; v < 16; ++v) o0[v] = o1[v] = negm[v] = 0.0f;
+            m_run = -INFINITY;
+            l_run = 0.0f;
+        }
+        // ---- prologue: tile 0 in slot 0, tile 1 on its way
+        stage_load(0);
+        stage_write(0);
+        if (ntiles > 1) stage_load(1);
+        __syncthreads();
+        // iterations t = 0 .. ntiles-2 bring in tile t+1; those with t+1 < nfull may take the fast form
+        int t = 0;
+        if (active) {
+            general_softmax(0, 0);
+            v_fragments(0);
+            if (pass == 0)
+                for (; t + 2 < nfull; t += 2) {  // t even: tile t+1 -> slot 1, tile t+2 -> slot 0, both full
+                    fast_step(1, t);
+                    fast_step(0, t + 1);
+                }
+            for (; t + 1 < ntiles; ++t) slow_step(t);
+            pv();  // the last tile
+        } else {
+            for (; t + 1 < ntiles; ++t) helper_step(t);
+        }
+    }
+
+    // ---- out[b, q, h*64 + d] = O^T[d][q] / l ; register v <-> channel (v&3) + 8*(v>>2) + 4*hf (+32)
+    const float l_tot = l_run + __shfl_xor(l_run, 32);
+    const float inv = 1.0f / l_tot;
+    if (qrow < a.N) {
+        short *op = reinterpret_cast<short *>(a.out) + b * a.o_sb + (int64_t)qrow * a.o_sn + h * a.o_sh + seg * a.o_seg;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            att_s16x4 w0, w1;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                w0[e] = att_bits<TX>(o0[4 * g + e] * inv);
+                w1[e] = att_bits<TX>(o1[4 * g + e] * inv);
+            }
+            *reinterpret_cast<att_s16x4 *>(op + 8 * g + 4 * hf) = w0;
+            *reinterpret_cast<att_s16x4 *>(op + 32 + 8 * g + 4 * hf) = w1;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // k_trajectory_mix: the temporal stage of Motionformer's trajectory attention as one streaming pass
 // (ToMeTrajectoryAttention.forward, tome/patch/motionformer.py:122-139):
 //     tattn = softmax_f( (q2 * scale) . k2[f] )          one logit per frame of the token's trajectory

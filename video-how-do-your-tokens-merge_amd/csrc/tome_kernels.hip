@@ -773,11 +773,16 @@ static int prop_attention_impl(const void *q, const void *k, const void *v, int 
 #define ATT_LAUNCH(TX, W, BI) hipLaunchKernelGGL((k_prop_attention<TX, W, BI>), grid, dim3(64 * W), 0, st, a)
 #define ATT_WAVES(TX, BI) \
     if (waves == 8) ATT_LAUNCH(TX, 8, BI); else ATT_LAUNCH(TX, 4, BI);
+    static const bool pipe_env = [] { const char *e = getenv("TOME_ATTN_PIPE"); return !(e && atoi(e) == 0); }();
+#define ATT_PLAIN(TX) \
+    if (waves == 8) hipLaunchKernelGGL((k_attention_plain<TX, 8>), grid, dim3(512), 0, st, a); \
+    else hipLaunchKernelGGL((k_attention_plain<TX, 4>), grid, dim3(256), 0, st, a);
     if (dtype == TOME_BF16) {
-        if (plain) { ATT_WAVES(bf16_t, false) } else { ATT_WAVES(bf16_t, true) }
+        if (plain && pipe_env) { ATT_PLAIN(bf16_t) } else if (plain) { ATT_WAVES(bf16_t, false) } else { ATT_WAVES(bf16_t, true) }
     } else {
-        if (plain) { ATT_WAVES(f16_t, false) } else { ATT_WAVES(f16_t, true) }
+        if (plain && pipe_env) { ATT_PLAIN(f16_t) } else if (plain) { ATT_WAVES(f16_t, false) } else { ATT_WAVES(f16_t, true) }
     }
+#undef ATT_PLAIN
 #undef ATT_WAVES
 #undef ATT_LAUNCH
     return check_launch("k_prop_attention");
