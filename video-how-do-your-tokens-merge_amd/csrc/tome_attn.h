@@ -393,9 +393,6 @@ __global__ __launch_bounds__(64 * WAVES) void k_prop_attention(AttnArgs a) {
 #ifndef ATT_ABL
 #define ATT_ABL 0  // measurement builds only (tools/ab_lib.sh): bit 0 no v_exp, 1 no barrier, 2 no V-fragment reads,
 #endif             // 3 no LDS staging writes, 4 no global loads in the fast step -- results are wrong by design
-#ifndef ATT_VARIANT
-#define ATT_VARIANT 0  // 0: the compiler orders the fast step; 1: hand-placed order behind scheduling fences
-#endif
 
 template <int V> struct AttInt { static constexpr int value = V; };
 
@@ -410,6 +407,8 @@ __global__ __launch_bounds__(64 * WAVES) void k_attention_plain(AttnArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int col = lane & 31, hf = lane >> 5;
     const int qblocks = (a.N + ATT_BM - 1) / ATT_BM;
+    // XCD-aware mapping: the query blocks of one (batch, head, segment) stream the same K/V -> same XCD (ids congruent
+    // mod 8).  (Measured: persistent workgroups walking a run of items each are 3 % slower than this.)
     const int L = blockIdx.x;
     const int xcd = L & 7, sq = L >> 3;
     const int bhs = (sq / qblocks) * 8 + xcd;
@@ -575,8 +574,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_attention_plain(AttnArgs a) {
     //   fast_step: tile t+1 holds 64 keys.  Straight-line code -- 16 MFMAs and ~80 vector instructions free to
     //   interleave.  The overflow guard only sets a flag (see below).
     bool bad = false;
-    att_s16x4 vfn[2][2][4];  // the V fragments of tile t+1 arrive here while the matrix pipe still reads vfr
-    auto fast_step = [&](int S, int t) __attribute__((always_inline)) {
+    auto fast_step = [&](int S, int t, bool masked) __attribute__((always_inline)) {
 #if !(ATT_ABL & 8)
         stage_write(S);  // registers hold tile t+1
 #endif
@@ -594,94 +592,8 @@ __global__ __launch_bounds__(64 * WAVES) void k_attention_plain(AttnArgs a) {
 #if !(ATT_ABL & 2)
         __syncthreads();   // tile t+1 visible; every wave has left iteration t-1
 #endif
-#if ATT_VARIANT == 1
-        // Hand-placed issue order, pinned by scheduling fences: every MFMA is followed by the vector work that can
-        // run in its shadow, so the matrix pipe and the softmax overlap inside the wave.
-        //   block 0 of the scores (4 MFMAs)                        | K and next V fragments are fetched
-        //   block 1 of the scores (4 MFMAs), each + 4 v_exp_f32 of block 0
-        //   O += V P (8 MFMAs), each + 2 v_exp_f32 of block 1 + 4 row-sum additions + 2 conversions
-        att_s16x8 kf[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-            kf[i] = *reinterpret_cast<const att_s16x8 *>(kbase + S * ATT_BN * ATT_KS + (i >> 2) * 32 * ATT_KS + 16 * (i & 3));
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int p = 0; p < 2; ++p) {
-                const short *va = vbase + S * ATT_BN * ATT_VS + (32 * kb + 16 * p) * ATT_VS;
-                vfn[kb][p][0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(va));
-                vfn[kb][p][1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(va + 8 * ATT_VS));
-                vfn[kb][p][2] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(va + 32));
-                vfn[kb][p][3] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(va + 8 * ATT_VS + 32));
-            }
-        s0 = AttMfma<TX>::run(kf[0], qf[0], negm);
-        s0 = AttMfma<TX>::run(kf[1], qf[1], s0);
-        s0 = AttMfma<TX>::run(kf[2], qf[2], s0);
-        s0 = AttMfma<TX>::run(kf[3], qf[3], s0);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            s1 = AttMfma<TX>::run(kf[4 + i], qf[i], i == 0 ? negm : s1);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) s0[4 * i + e] = __builtin_amdgcn_exp2f(s0[4 * i + e]);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        float cs[4];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int kb = j >> 2, p = (j >> 1) & 1, half = j & 1;
-            att_s16x8 vf;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                vf[e] = vfr[kb][p][2 * half][e];
-                vf[4 + e] = vfr[kb][p][2 * half + 1][e];
-            }
-            if (half == 0) o0 = AttMfma<TX>::run(vf, pf[kb][p], o0);
-            else o1 = AttMfma<TX>::run(vf, pf[kb][p], o1);
-            s1[2 * j] = __builtin_amdgcn_exp2f(s1[2 * j]);
-            s1[2 * j + 1] = __builtin_amdgcn_exp2f(s1[2 * j + 1]);
-            // row-sum additions whose operands are ready (four chains over register index mod 4)
-            if (j == 0) {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) cs[k] = att_add(s0[k], s0[4 + k]);
-            } else if (j == 1 || j == 2) {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) cs[k] = att_add(cs[k], s0[4 * (j + 1) + k]);
-            } else if (j >= 3 && j <= 5) {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) cs[k] = att_add(cs[k], s1[4 * (j - 3) + k]);
-            } else if (j == 6) {
-                cs[0] = att_add(cs[0], s1[12]);
-                cs[1] = att_add(cs[1], s1[13]);
-            }
-            // conversions into the P fragments the matrix pipe has finished reading
-            if (j == 2 || j == 3) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) pf[0][0][4 * (j - 2) + e] = att_bits<TX>(s0[4 * (j - 2) + e]);
-            } else if (j == 4 || j == 5) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) pf[0][1][4 * (j - 4) + e] = att_bits<TX>(s0[8 + 4 * (j - 4) + e]);
-            } else if (j == 6 || j == 7) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) pf[1][0][4 * (j - 6) + e] = att_bits<TX>(s1[4 * (j - 6) + e]);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        cs[2] = att_add(cs[2], s1[14]);
-        cs[3] = att_add(cs[3], s1[15]);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) pf[1][1][e] = att_bits<TX>(s1[8 + e]);
-        const float lsum = att_add(att_add(cs[0], cs[1]), att_add(cs[2], cs[3]));
-        l_run += lsum;
-        bad = bad || !(lsum <= AttLimit<TX>::value);  // inf / NaN / too large: this pass is void (rerun below)
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int p = 0; p < 2; ++p)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) vfr[kb][p][q] = vfn[kb][p][q];
-#else
-        // compiler-scheduled form of the same work
+        // (measured: a hand-placed issue order of this block -- every MFMA followed by the vector work that fits its
+        // shadow, pinned by sched_barrier fences -- runs within 1 % of what the compiler makes of it)
         scores(S, negm);
         pv();
 #if !(ATT_ABL & 4)
@@ -693,6 +605,15 @@ __global__ __launch_bounds__(64 * WAVES) void k_attention_plain(AttnArgs a) {
 #pragma unroll
         for (int v = 0; v < 16; ++v) s1[v] = __builtin_amdgcn_exp2f(s1[v]);
 #endif
+        if (masked) {  // the partly filled last tile: keys past the end weigh nothing
+            const int key0 = (t + 1) * ATT_BN + 4 * hf;
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int key = key0 + (v & 3) + 8 * (v >> 2);
+                s0[v] = key < a.Nk ? s0[v] : 0.0f;
+                s1[v] = key + 32 < a.Nk ? s1[v] : 0.0f;
+            }
+        }
         float c0s = att_add(s0[0], s0[4]), c1s = att_add(s0[1], s0[5]), c2s = att_add(s0[2], s0[6]),
               c3s = att_add(s0[3], s0[7]);
 #pragma unroll
@@ -709,7 +630,6 @@ __global__ __launch_bounds__(64 * WAVES) void k_attention_plain(AttnArgs a) {
         pack_p();
         l_run += lsum;
         bad = bad || !(lsum <= AttLimit<TX>::value);  // inf / NaN / too large: this pass is void (rerun below)
-#endif
     };
     //   slow_step: any tile t+1 (partly filled, or the general pass): general softmax, run-time slot.
     auto slow_step = [&](int t) __attribute__((always_inline)) {
@@ -750,11 +670,15 @@ __global__ __launch_bounds__(64 * WAVES) void k_attention_plain(AttnArgs a) {
         if (active) {
             general_softmax(0, 0);
             v_fragments(0);
-            if (pass == 0)
+            if (pass == 0) {
                 for (; t + 2 < nfull; t += 2) {  // t even: tile t+1 -> slot 1, tile t+2 -> slot 0, both full
-                    fast_step(1, t);
-                    fast_step(0, t + 1);
+                    fast_step(1, t, false);
+                    fast_step(0, t + 1, false);
                 }
+                // at most two tiles left -- a last full one, a partly filled one: the same step with a run-time slot
+                // and the weights of keys past the end forced to zero (one more copy of the code, not four)
+                for (; t + 1 < ntiles; ++t) fast_step((t + 1) & 1, t, true);
+            }
             for (; t + 1 < ntiles; ++t) slow_step(t);
             pv();  // the last tile
         } else {
