@@ -233,6 +233,9 @@ __global__ __launch_bounds__(256) void k_unit_rows_generic(const T *__restrict__
 // ------------------------------------------------------------------------------------------------
 #define TILE_ROWS 32
 #define MAX_WJ 8
+#ifndef SCORES_BBUF
+#define SCORES_BBUF 4  // float4 of the B stream in flight per lane (8 = a whole step ahead, 4 = half a step)
+#endif
 
 struct RowBest {
     float best;
@@ -270,8 +273,13 @@ __device__ __forceinline__ void fold_tile(const f32x16 &acc, RowBest &rb, int jt
 __device__ unsigned long long g_diag_stamps[TOME_DIAG_SLOTS * 2];
 #endif
 
+#ifndef SCORES_WAVES
+#define SCORES_WAVES 5  // waves per SIMD the register allocation aims at.  Measured at batch 128 (12 layers of VideoMAE-B,
+                        // profiles/r02_scores_occupancy.txt): 8 float4 / 4 waves (106 VGPRs) 99.0 TF/s; 4 float4 / 5 waves
+                        // (94 VGPRs) 100.4; 4 float4 / 6 waves (80 VGPRs, 60 B of scratch) 77.3 -- occupancy is not the lever
+#endif
 template <bool ONE_CHUNK>
-__global__ __launch_bounds__(64) void k_scores_rowmax(const f32x4 *__restrict__ unitA,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SCORES_WAVES, 8))) void k_scores_rowmax(const f32x4 *__restrict__ unitA,
                                                       const f32x4 *__restrict__ unitB, int n, int T1, int T2,
                                                       int nchunk, int ntA, int ntB, int WJ, int64_t groupA_f4,
                                                       int64_t groupB_f4, int distill_token,
@@ -302,19 +310,20 @@ __global__ __launch_bounds__(64) void k_scores_rowmax(const f32x4 *__restrict__ 
     const unsigned long long diag_c0 = __builtin_amdgcn_s_memtime(), diag_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
     if (nstep > 0) {
-        f32x4 af[8], bt[8];
+        // B operands: SCORES_BBUF float4 in flight (8: a whole step ahead; 4: half a step ahead, 16 registers
+        // fewer -- the form that reaches six waves per SIMD).  Each float4 is replaced right after its last use.
+        constexpr int NB = SCORES_BBUF;
+        f32x4 af[8], bt[NB];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            af[q] = atile[q * 64];
-            bt[q] = bstream[q * 64];
-        }
+        for (int q = 0; q < 8; ++q) af[q] = atile[q * 64];
+#pragma unroll
+        for (int q = 0; q < NB; ++q) bt[q] = bstream[q * 64];
         f32x16 acc;
         int jt = jt0, c = 0;
         for (int step = 0; step < nstep; ++step) {
-            // operands of the NEXT step replace each float4 right after its last use (single register
-            // buffer, each load has 7/8 of a step to land); the last step re-reads its own block
+            // the last step re-reads its own block instead of running past the stream
             const int nx = step + 1 < nstep ? step + 1 : step;
-            const f32x4 *nb = bstream + (int64_t)nx * 512;
+            const f32x4 *cb = bstream + (int64_t)step * 512, *nb = bstream + (int64_t)nx * 512;
             const int cn = (c + 1 == nchunk) ? 0 : c + 1;
             if (c == 0) {
 #pragma unroll
@@ -322,12 +331,13 @@ __global__ __launch_bounds__(64) void k_scores_rowmax(const f32x4 *__restrict__ 
             }
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
-                const f32x4 b = bt[q], a = af[q];
+                const f32x4 b = bt[q % NB], a = af[q];
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.x, a.x, acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.y, a.y, acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.z, a.z, acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.w, a.w, acc, 0, 0, 0);
-                bt[q] = nb[q * 64];
+                // element q + NB of the stream: this step's second half (NB = 4, q < 4) or the next step's
+                bt[q % NB] = (q + NB < 8) ? cb[(q + NB) * 64] : nb[(q + NB - 8) * 64];
                 if (!ONE_CHUNK) af[q] = atile[(cn * 8 + q) * 64];
                 __builtin_amdgcn_sched_barrier(0);
             }
