@@ -21,7 +21,9 @@ def topk_counts(logits: torch.Tensor, labels: torch.Tensor, ks=(1, 5)) -> torch.
     top = logits.float().topk(kmax, dim=1).indices
     hit = top == labels[:, None]
     out = [hit[:, :k].any(dim=1).sum() for k in ks]
-    out.append(torch.tensor(logits.shape[0], device=logits.device))
+    # (the clip count is made on the device by a fill, not copied from a host scalar: the step stays capturable in a
+    # HIP graph)
+    out.append(torch.full((), logits.shape[0], dtype=torch.int64, device=logits.device))
     return torch.stack([o.to(torch.int64) for o in out])
 
 
