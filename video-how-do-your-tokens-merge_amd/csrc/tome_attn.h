@@ -397,7 +397,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_prop_attention(AttnArgs a) {
 template <int V> struct AttInt { static constexpr int value = V; };
 
 template <typename TX, int WAVES>
-__global__ __launch_bounds__(64 * WAVES) void k_attention_plain(AttnArgs a) {
+__global__ __launch_bounds__(64 * WAVES, 2) void k_attention_plain(AttnArgs a) {  // two waves per SIMD either way
     constexpr int ATT_BM = 32 * WAVES;
     // two LDS slots: tile t lives in slot t & 1.  Tile t+1 is written during iteration t, when every wave has left
     // iteration t-2 -- the last one that read slot (t+1) & 1 (K(t-1) for its scores, V(t-1) into registers).

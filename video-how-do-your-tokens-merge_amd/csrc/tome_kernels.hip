@@ -763,7 +763,10 @@ static int prop_attention_impl(const void *q, const void *k, const void *v, int 
         int v = e ? atoi(e) : 0;
         return (v == 4 || v == 8) ? v : 0;
     }();
-    const int waves = waves_env ? waves_env : (N > 128 ? 8 : 4);
+    // (the pipelined plain kernel keeps two waves per SIMD either way: two 4-wave workgroups share a CU.  They lose
+    // 3-5 % on long launches -- every tile is staged twice per CU -- and win 7-13 % when the launch is short: fewer
+    // than four rounds of 8-wave workgroups over the 256 CUs)
+    const int waves = waves_env ? waves_env : ((N > 128 && B * H * nseg * ((N + 255) / 256) >= 1024) || log_size ? (N > 128 ? 8 : 4) : 4);
     const int64_t qblocks = (N + 32 * waves - 1) / (32 * waves);
     const int64_t bh8 = (B * H * nseg + 7) / 8 * 8;
     if (bh8 * qblocks > 0x7fffffffLL) return fail(TOME_EINVAL, "tome_prop_attention: grid too large");
