@@ -766,27 +766,20 @@ static int prop_attention_impl(const void *q, const void *k, const void *v, int 
     // (the pipelined plain kernel keeps two waves per SIMD either way: two 4-wave workgroups share a CU.  They lose
     // 3-5 % on long launches -- every tile is staged twice per CU -- and win 7-13 % when the launch is short: fewer
     // than four rounds of 8-wave workgroups over the 256 CUs)
-    const int waves = waves_env ? waves_env : ((N > 128 && B * H * nseg * ((N + 255) / 256) >= 1024) || log_size ? (N > 128 ? 8 : 4) : 4);
+    const int waves = waves_env ? waves_env : ((N > 128 && B * H * nseg * ((N + 255) / 256) >= 1024) ? 8 : 4);
     const int64_t qblocks = (N + 32 * waves - 1) / (32 * waves);
     const int64_t bh8 = (B * H * nseg + 7) / 8 * 8;
     if (bh8 * qblocks > 0x7fffffffLL) return fail(TOME_EINVAL, "tome_prop_attention: grid too large");
     const dim3 grid((unsigned)(bh8 * qblocks));
     hipStream_t st = (hipStream_t)stream;
-    const bool plain = !log_size;  // no per-key term: the accumulator-start softmax (tome_attn.h)
-#define ATT_LAUNCH(TX, W, BI) hipLaunchKernelGGL((k_prop_attention<TX, W, BI>), grid, dim3(64 * W), 0, st, a)
-#define ATT_WAVES(TX, BI) \
-    if (waves == 8) ATT_LAUNCH(TX, 8, BI); else ATT_LAUNCH(TX, 4, BI);
-    static const bool pipe_env = [] { const char *e = getenv("TOME_ATTN_PIPE"); return !(e && atoi(e) == 0); }();
-#define ATT_PLAIN(TX) \
-    if (waves == 8) hipLaunchKernelGGL((k_attention_plain<TX, 8>), grid, dim3(512), 0, st, a); \
-    else hipLaunchKernelGGL((k_attention_plain<TX, 4>), grid, dim3(256), 0, st, a);
+#define ATT_LAUNCH(TX, BI)                                                                        \
+    if (waves == 8) hipLaunchKernelGGL((k_prop_attention<TX, 8, BI>), grid, dim3(512), 0, st, a); \
+    else hipLaunchKernelGGL((k_prop_attention<TX, 4, BI>), grid, dim3(256), 0, st, a);
     if (dtype == TOME_BF16) {
-        if (plain && pipe_env) { ATT_PLAIN(bf16_t) } else if (plain) { ATT_WAVES(bf16_t, false) } else { ATT_WAVES(bf16_t, true) }
+        if (log_size) { ATT_LAUNCH(bf16_t, true) } else { ATT_LAUNCH(bf16_t, false) }
     } else {
-        if (plain && pipe_env) { ATT_PLAIN(f16_t) } else if (plain) { ATT_WAVES(f16_t, false) } else { ATT_WAVES(f16_t, true) }
+        if (log_size) { ATT_LAUNCH(f16_t, true) } else { ATT_LAUNCH(f16_t, false) }
     }
-#undef ATT_PLAIN
-#undef ATT_WAVES
 #undef ATT_LAUNCH
     return check_launch("k_prop_attention");
 }
