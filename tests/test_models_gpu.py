@@ -333,6 +333,41 @@ def test_duplicate_layer_patches():
     assert torch.isfinite(out).all() and model._tome_info["size"].shape[1] == 32 - 10
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_vivit_duplicate_layer_patch(dtype):
+    """tome.patch.duplicate_vivit (tome/patch/vivit.py:207-211): deep copies that only attend + merge are inserted in
+    front of the duplicated layer, `config.num_hidden_layers` grows by `quantity` as in the reference, the per-layer r
+    list walks the expected token counts, and the result equals running the layer's attention + merge by hand.  (No
+    reference fixture: the reference's ViViT patch cannot be imported here, SURVEY.md 8c -- parity unpinned.)  The
+    16-bit run also crosses a duplicated layer with the fused residual / LayerNorm hand-over switched on."""
+    tome, H = _hosts()
+    torch.manual_seed(0)
+    model = H["vivit"].ViViT(num_classes=5, image_size=64, num_frames=8, hidden_size=128, num_hidden_layers=3,
+                             num_attention_heads=2, intermediate_size=256).to(DEV).to(dtype).eval()
+    before = model.vivit.config.num_hidden_layers
+    tome.patch.duplicate_vivit(model, 1, 3)
+    assert len(model.vivit.encoder.layer) == 5 and model.vivit.config.num_hidden_layers == before + 3
+    tome.patch.vivit(model)
+    clip = torch.rand(2, 3, 8, 64, 64, device=DEV).to(dtype)
+    tokens = 1 + 4 * 16
+    out, plans = _trace(tome, model, clip, [0, 6, 6, 6, 0])
+    assert out.shape == (2, 5) and torch.isfinite(out).all()
+    assert [s[1] for s, _ in plans] == [tokens, tokens - 6, tokens - 12]
+    assert float(model._tome_info["size"].float().sum()) == 2.0 * tokens
+    for _, p in plans:  # the class token is never merged and stays first
+        assert int(p.unm_idx[0, 0, 0]) == 0 and bool((p.src_idx != 0).all())
+    # r = 0 everywhere: the duplicates only attend (their output is dropped), the model equals the un-duplicated one
+    torch.manual_seed(0)
+    plain = H["vivit"].ViViT(num_classes=5, image_size=64, num_frames=8, hidden_size=128, num_hidden_layers=3,
+                             num_attention_heads=2, intermediate_size=256).to(DEV).to(dtype).eval()
+    tome.patch.vivit(plain)
+    plain.r = 0
+    model.r = 0
+    with torch.no_grad():
+        want, got = plain([clip]), model([clip])
+    assert torch.equal(want, got)
+
+
 def test_graphed_forward_replays_the_merge_path():
     """The whole patched forward, merge kernels included, captured in a HIP graph and replayed on new clips:
     same logits as the eager run (the merge path launches on torch's current stream, allocates through

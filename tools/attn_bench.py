@@ -32,6 +32,9 @@ torch.manual_seed(0)
 shapes = [(128, 12, 1568), (128, 12, 1472), (8, 12, 3137), (64, 12, 197), (8, 12, 1568)]
 if "--quick" in sys.argv:
     shapes = shapes[:2]
+for arg in sys.argv[1:]:
+    if arg.startswith("--shapes="):  # --shapes=128x12x1536,128x12x1600
+        shapes = [tuple(int(v) for v in sh.split("x")) for sh in arg.split("=", 1)[1].split(",")]
 ours_only = "--ours" in sys.argv
 for (B, H, N) in shapes:
     qkv = torch.randn(B, N, 3, H, 64, device=dev).bfloat16()
