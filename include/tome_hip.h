@@ -39,7 +39,7 @@ enum tome_status {
     TOME_ELAUNCH = 3     /* HIP reported a launch error (text in tome_last_error()) */
 };
 
-#define TOME_ABI_VERSION 4
+#define TOME_ABI_VERSION 5
 
 int tome_abi_version(void);
 
@@ -159,13 +159,18 @@ int tome_merge_wavg_regrouped(const void *x, int x_dtype, const void *size, int 
 
 /* tome_merge_wavg_regrouped with the residual add in front and the block's norm2 behind it fused in, as
  * tome_merge_wavg_ln does for the plain layout (timesformer.py:52-56, motionformer.py:24-29).  The class-token
- * rows get the same add + LayerNorm.  16-bit tokens, C <= 1024. */
+ * rows get the same add + LayerNorm.  16-bit tokens, C <= 1024.
+ * addend: NULL, or the residual in x's layout [B, has_cls + P*F, C] (addend_grouped = 0), or -- addend_grouped = 1 --
+ * in the GROUPED layout [B*F, has_cls + P, C] the spatial attention of TimeSformer leaves it in
+ * (tome/patch/timesformer.py:32-52: `res_spatial`, whose '(b t) (h w) m -> b (h w t) m' rearrangement and `cat` with
+ * the frame-averaged class token are then not made); its class rows are ignored and the class tokens' addend is
+ * cls_addend [B, C] (NULL: none). */
 int tome_merge_wavg_regrouped_ln(const void *x, int x_dtype, const void *size, int size_dtype, int64_t B,
                                  int64_t F, int64_t P, int64_t C, int64_t r, int has_cls,
                                  const int64_t *src_idx, const int64_t *dst_idx, const int64_t *unm_idx,
                                  const uint8_t *edge_keep, const void *ln_weight, const void *ln_bias, float eps,
-                                 const void *addend, void *x_out, void *y_out, void *size_out,
-                                 void *log_size_out, tome_stream_t stream);
+                                 const void *addend, int addend_grouped, const void *cls_addend, void *x_out,
+                                 void *y_out, void *size_out, void *log_size_out, tome_stream_t stream);
 
 /* tome_drop (below) on the regrouped layout of tome_merge_wavg_regrouped: timesformer_drop / motionformer_drop
  * (tome/patch/timesformer.py:111-131, motionformer.py:172-193) without the permuted copies.

@@ -644,6 +644,16 @@ def test_merge_wavg_regrouped_ln(B, F, P, C, r, dtype):
     ref = torch.nn.functional.layer_norm(want_x.float(), (C,), w.float(), b.float(), 1e-6)
     tol = 2 ** -7 if dtype == torch.bfloat16 else 2 ** -10
     assert float(((got_y.float() - ref).abs() / ref.abs().clamp(min=1.0)).max()) <= tol
+    # the same residual handed over where TimeSformer's spatial attention leaves it -- [(b f), 1 + p, C] with a class
+    # row per frame (ignored) plus the class tokens' own addend [B, 1, C] -- must give the same bits as the
+    # '(b f) p -> b (p f)' rearranged + concatenated tensor (tome/patch/timesformer.py:40-52)
+    from einops import rearrange
+    grouped = torch.cat((dev(synth.normal_like((B * F, 1, C), seed + 11), dtype),
+                         rearrange(res[:, 1:], "b (p f) c -> (b f) p c", f=F)), 1).contiguous()
+    alt = _abi.merge_wavg_regrouped(plan, x_full, size, F, has_cls=True, ln=(w, b, 1e-6), addend_grouped=grouped,
+                                    cls_addend=res[:, :1].contiguous())
+    for g_, w_ in zip(alt, (got_x, got_y, got_s)):
+        assert torch.equal(g_, w_)
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.bfloat16, 2 ** -7), (torch.float16, 2 ** -10)])

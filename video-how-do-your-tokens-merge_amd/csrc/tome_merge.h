@@ -36,6 +36,13 @@ struct LnArgs {
     float eps;
     const void *addend;         // optional [n, T, C]: the tokens that are merged are round(x + addend), i.e. the
                                 // block's residual `x = x + attn(...)` (videomae.py:20,25) is taken on the fly
+    // The addend may live in a layout of its own (a_own): TimeSformer's second residual is the spatial attention's
+    // output [(b t), 1 + p, m] (timesformer.py:40-52), read where it lies instead of being permuted to 'b (p t) m'
+    // first; the class rows' addend (the class token averaged over the frames, timesformer.py:42-44) is then a
+    // separate [B, C] tensor.
+    int a_own;
+    TokLayout la;
+    const void *cls_addend;
 };
 
 // round(x + a) in the token dtype, element-wise on two 16-byte packs (what torch's `x + a` stores)
@@ -78,7 +85,8 @@ __device__ __forceinline__ void merge_dst_row(const TX *__restrict__ xg, const T
                                               const int64_t *__restrict__ dstg, const uint8_t *__restrict__ keep,
                                               TX *__restrict__ orow, TS *__restrict__ srow, int lane,
                                               const LnArgs *ln = nullptr, TX *__restrict__ yrow = nullptr,
-                                              const TX *__restrict__ ag = nullptr, TS *__restrict__ lrow = nullptr) {
+                                              const TX *__restrict__ ag = nullptr, TS *__restrict__ lrow = nullptr,
+                                              int64_t astride = 0) {
     const int t = 2 * j + 1;
     const TX *xr = xg + (int64_t)t * tstride;
     float s_own = 1.0f;
@@ -92,7 +100,7 @@ __device__ __forceinline__ void merge_dst_row(const TX *__restrict__ xg, const T
         typedef Pack<TX, VEC> __attribute__((aligned(sizeof(TX) * VEC))) PKA;
         float acc0[VEC], acc1[VEC];
         if (LN && ag) {
-            const TX *ar = ag + (int64_t)t * tstride;
+            const TX *ar = ag + (int64_t)t * astride;
             PKA x0, x1, y0, y1;
             if (a0) { x0 = *reinterpret_cast<const PKA *>(xr + c0); y0 = *reinterpret_cast<const PKA *>(ar + c0); }
             if (a1) { x1 = *reinterpret_cast<const PKA *>(xr + c1); y1 = *reinterpret_cast<const PKA *>(ar + c1); }
@@ -162,7 +170,7 @@ __device__ __forceinline__ void merge_dst_row(const TX *__restrict__ xg, const T
                         if (a0) p0[u] = *reinterpret_cast<const PK *>(sr + c0);
                         if (a1) p1[u] = *reinterpret_cast<const PK *>(sr + c1);
                         if (LN && ag) {
-                            const TX *sa = ag + (int64_t)tsu * tstride;
+                            const TX *sa = ag + (int64_t)tsu * astride;
                             if (a0) q0[u] = *reinterpret_cast<const PK *>(sa + c0);
                             if (a1) q1[u] = *reinterpret_cast<const PK *>(sa + c1);
                         }
@@ -433,9 +441,10 @@ __global__ __launch_bounds__(256) void k_merge_rows_fast(const TX *__restrict__ 
                 uint4 r0 = a0 ? src[c0] : uint4{0, 0, 0, 0}, r1 = a1 ? src[c1] : uint4{0, 0, 0, 0};
                 __builtin_memcpy(&p0, &r0, 16);
                 __builtin_memcpy(&p1, &r1, 16);
-                if (ln.addend) {
-                    const uint4 *asrc = reinterpret_cast<const uint4 *>(reinterpret_cast<const TX *>(ln.addend) +
-                                                                        b * lin.outer_stride);
+                if (ln.a_own ? ln.cls_addend != nullptr : ln.addend != nullptr) {
+                    const uint4 *asrc = ln.a_own
+                        ? reinterpret_cast<const uint4 *>(reinterpret_cast<const TX *>(ln.cls_addend) + b * (int64_t)C)
+                        : reinterpret_cast<const uint4 *>(reinterpret_cast<const TX *>(ln.addend) + b * lin.outer_stride);
                     Pack<TX, VEC> q0, q1;
                     uint4 s0 = a0 ? asrc[c0] : uint4{0, 0, 0, 0}, s1 = a1 ? asrc[c1] : uint4{0, 0, 0, 0};
                     __builtin_memcpy(&q0, &s0, 16);
@@ -505,8 +514,8 @@ __global__ __launch_bounds__(256) void k_merge_rows_fast(const TX *__restrict__ 
             src_idx + (int64_t)g * r, dstg, keep, group_ptr(xout, lout, g) + (int64_t)o * lout.tok_stride,
             sout ? sout + (int64_t)g * To + o : nullptr, lane, &ln,
             LN ? group_ptr(reinterpret_cast<TX *>(ln.y), lout, g) + (int64_t)o * lout.tok_stride : nullptr,
-            (LN && ln.addend) ? group_ptr(reinterpret_cast<const TX *>(ln.addend), lin, g) : nullptr,
-            lsout ? lsout + (int64_t)g * To + o : nullptr);
+            (LN && ln.addend) ? group_ptr(reinterpret_cast<const TX *>(ln.addend), ln.a_own ? ln.la : lin, g) : nullptr,
+            lsout ? lsout + (int64_t)g * To + o : nullptr, ln.a_own ? ln.la.tok_stride : lin.tok_stride);
         return;
     }
     const int g = (int)(w / rg_per_group);
@@ -584,7 +593,8 @@ __global__ __launch_bounds__(256) void k_merge_rows_fast(const TX *__restrict__ 
                                                        cc * 16);
     }
     if (LN && ln.addend) {  // fused residual: the rows that are merged are round(x + addend)
-        const TX *agp = group_ptr(reinterpret_cast<const TX *>(ln.addend), lin, g);
+        const TX *agp = group_ptr(reinterpret_cast<const TX *>(ln.addend), ln.a_own ? ln.la : lin, g);
+        const int64_t astride = ln.a_own ? ln.la.tok_stride : lin.tok_stride;
         uint4 rawa[NIT];
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
@@ -593,8 +603,7 @@ __global__ __launch_bounds__(256) void k_merge_rows_fast(const TX *__restrict__ 
             const int q = it * WAVE + lane;
             const int cc = q - rr * cpr;
             const int t = rr == 0 ? tok0 : (rr == 1 ? tok1 : (rr == 2 ? tok2 : tok3));
-            rawa[it] = *reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(agp + (int64_t)t * lin.tok_stride) +
-                                                        cc * 16);
+            rawa[it] = *reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(agp + (int64_t)t * astride) + cc * 16);
         }
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {

@@ -25,7 +25,7 @@ SYMBOLS = (
     "tome_profile_enable", "tome_profile_read",
 )
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 DTYPES = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}
 MODES = {"sum": 0, "mean": 1, "amax": 2, "max": 2, "prod": 3, "amin": 4, "min": 4}
 
@@ -75,7 +75,7 @@ def lib() -> ctypes.CDLL:
                                             vp]
     L.tome_merge_wavg_regrouped_ln.restype = i32
     L.tome_merge_wavg_regrouped_ln.argtypes = [vp, i32, vp, i32, i64, i64, i64, i64, i64, i32, vp, vp, vp, vp, vp, vp,
-                                               ctypes.c_float, vp, vp, vp, vp, vp, vp]
+                                               ctypes.c_float, vp, i32, vp, vp, vp, vp, vp, vp]
     L.tome_add_layernorm.restype = i32
     L.tome_add_layernorm.argtypes = [vp, vp, i32, i64, i64, vp, vp, ctypes.c_float, vp, vp, vp]
     L.tome_add_layernorm_regrouped.restype = i32
@@ -447,7 +447,8 @@ def add_layernorm_regrouped(x: torch.Tensor, addend: torch.Tensor, frames: int, 
 
 def merge_wavg_regrouped(plan: MatchPlan, x_full: torch.Tensor, size: Optional[torch.Tensor], frames: int,
                          has_cls: bool = True, ln=None, addend: Optional[torch.Tensor] = None,
-                         log_size: bool = False):
+                         log_size: bool = False, addend_grouped: Optional[torch.Tensor] = None,
+                         cls_addend: Optional[torch.Tensor] = None):
     """merge_wavg on the interleaved layout of TimeSformer / Motionformer: x_full [B, has_cls + P*F, C] whose
     token has_cls + p*F + f belongs to group b*F + f; returns x_out [B, has_cls + (P-r)*F, C] and size
     [B*F, P-r, 1].  Replaces rearrange -> merge_wavg -> rearrange -> cat (timesformer.py:89-107).
@@ -481,7 +482,7 @@ def merge_wavg_regrouped(plan: MatchPlan, x_full: torch.Tensor, size: Optional[t
     s_out = torch.empty((plan.n, P - plan.r, 1), dtype=sdtype, device=x_full.device)
     log = _log_size_like(s_out, log_size)
     if ln is None:
-        if addend is not None:
+        if addend is not None or addend_grouped is not None:
             raise TomeHipError("merge_wavg_regrouped: addend is only fused together with ln")
         with _on_device(x_full.device):
             rc = lib().tome_merge_wavg_regrouped(x_full.data_ptr(), xcode, _ptr(size), DTYPES[sdtype], B, F, P, C,
@@ -491,7 +492,21 @@ def merge_wavg_regrouped(plan: MatchPlan, x_full: torch.Tensor, size: Optional[t
         _check(rc, "tome_merge_wavg_regrouped")
         return x_out, s_out
     weight, bias, eps = ln
-    if addend is not None:
+    grouped = 0
+    if addend_grouped is not None:
+        # the residual where the spatial attention left it: [B*F, has_cls + P, C] (+ the class tokens' own [B, 1, C])
+        if addend is not None:
+            raise TomeHipError("merge_wavg_regrouped: pass addend or addend_grouped, not both")
+        if tuple(addend_grouped.shape) != (plan.n, cls + P, C) or addend_grouped.dtype != x_full.dtype \
+                or addend_grouped.device != x_full.device:
+            raise TomeHipError(f"merge_wavg_regrouped: addend_grouped must be {(plan.n, cls + P, C)} of x's dtype")
+        addend = addend_grouped if addend_grouped.is_contiguous() else addend_grouped.contiguous()
+        grouped = 1
+        if cls_addend is not None:
+            if cls_addend.numel() != B * C or cls_addend.dtype != x_full.dtype or cls_addend.device != x_full.device:
+                raise TomeHipError(f"merge_wavg_regrouped: cls_addend must hold {(B, C)} values of x's dtype")
+            cls_addend = cls_addend.contiguous()
+    elif addend is not None:
         if addend.shape != x_full.shape or addend.dtype != x_full.dtype or addend.device != x_full.device:
             raise TomeHipError("merge_wavg_regrouped: addend must match x in shape, dtype and device")
         addend = addend if addend.is_contiguous() else addend.contiguous()
@@ -500,7 +515,8 @@ def merge_wavg_regrouped(plan: MatchPlan, x_full: torch.Tensor, size: Optional[t
         rc = lib().tome_merge_wavg_regrouped_ln(x_full.data_ptr(), xcode, _ptr(size), DTYPES[sdtype], B, F, P, C,
                                                 plan.r, cls, plan.src_idx.data_ptr(), plan.dst_idx.data_ptr(),
                                                 plan.unm_idx.data_ptr(), _ptr(plan.edge_keep), weight.data_ptr(),
-                                                bias.data_ptr(), float(eps), _ptr(addend), x_out.data_ptr(),
+                                                bias.data_ptr(), float(eps), _ptr(addend), grouped,
+                                                _ptr(cls_addend) if grouped else None, x_out.data_ptr(),
                                                 y_out.data_ptr(), s_out.data_ptr(), _ptr(log),
                                                 _stream(x_full.device))
     _check(rc, "tome_merge_wavg_regrouped_ln")

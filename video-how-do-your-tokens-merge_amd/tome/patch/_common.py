@@ -210,31 +210,61 @@ def reduce_merge_regrouped(metric, x_full, info, r, frames, hybrid=False):
     return x_out
 
 
+class GroupedResidual:
+    """TimeSformer's second residual as the spatial attention leaves it (tome/patch/timesformer.py:32-52): `rs`
+    [(b t), 1 + p, m] with a class row per frame, and the class token averaged over the frames `cls_new` [b, 1, m].
+    The reference rearranges it '(b t) p m -> b (p t) m' and concatenates; the fused merge kernel reads it where it
+    lies (`addend_grouped`), anything else asks for `.materialize()`."""
+
+    def __init__(self, rs: torch.Tensor, cls_new: torch.Tensor, B: int, T: int, P: int):
+        self.rs, self.cls_new, self.B, self.T, self.P = rs, cls_new, B, T, P
+        self.dtype = rs.dtype
+
+    def materialize(self) -> torch.Tensor:
+        B, T, P, m = self.B, self.T, self.P, self.rs.shape[-1]
+        body = self.rs.reshape(B, T, 1 + P, m)[:, :, 1:, :].transpose(1, 2)  # '(b t) p -> b p t', still a view
+        if torch.is_grad_enabled() and self.rs.requires_grad:
+            return torch.cat((self.cls_new, body.reshape(B, P * T, m)), 1)
+        res = torch.empty((B, 1 + P * T, m), dtype=self.rs.dtype, device=self.rs.device)
+        res[:, :1, :] = self.cls_new  # assembled by one strided copy
+        res[:, 1:, :].view(B, P, T, m).copy_(body)
+        return res
+
+
 def merge_then_norm_regrouped(metric, x_full, info, norm, unfused_reduce, is_plain_merge: bool, frames: int,
                               residual=None):
     """merge_then_norm for the interleaved layouts (TimeSformer '(p t)', Motionformer '(s f)'): x_full is
-    [B, 1 + P*F, C]; `unfused_reduce(x)` is the model's own reduction step (it pops r itself)."""
+    [B, 1 + P*F, C]; `unfused_reduce(x)` is the model's own reduction step (it pops r itself).  `residual`: a tensor
+    in x's layout, or a GroupedResidual."""
     from .. import _abi
     from ..merge import do_nothing
     r_list = info["r"]
     fusable = (_FUSE_LN and is_plain_merge and r_list and r_list[0] > 0 and info["mode"] == "merge"
                and not info["trace_source"] and _abi.ln_fusable(x_full, norm)
                and _abi.effective_r((x_full.shape[1] - 1) // frames, r_list[0], False, False) > 0)
+    grouped = residual if isinstance(residual, GroupedResidual) else None
+    if grouped is not None and not (fusable and _FUSE_ADD and grouped.dtype == x_full.dtype):
+        residual, grouped = grouped.materialize(), None
     if not fusable:
         if residual is not None:
             x_full = x_full + residual
         x_full = unfused_reduce(x_full)
         return x_full, norm(x_full)
-    if residual is not None and (not _FUSE_ADD or residual.dtype != x_full.dtype):
+    if grouped is None and residual is not None and (not _FUSE_ADD or residual.dtype != x_full.dtype):
         x_full = x_full + residual
         residual = None
     r = r_list.pop(0)
     merge, _ = bipartite_soft_matching(metric, r, info["class_token"], info["distill_token"], info["mode"])
     assert merge is not do_nothing
     plan = merge.plan
-    x_out, y_out, info["size"] = _abi.merge_wavg_regrouped(plan, x_full, info["size"], frames, has_cls=True,
-                                                          ln=(norm.weight, norm.bias, norm.eps), addend=residual,
-                                                          log_size=info["prop_attn"])
+    if grouped is not None:
+        x_out, y_out, info["size"] = _abi.merge_wavg_regrouped(
+            plan, x_full, info["size"], frames, has_cls=True, ln=(norm.weight, norm.bias, norm.eps),
+            addend_grouped=grouped.rs, cls_addend=grouped.cls_new, log_size=info["prop_attn"])
+    else:
+        x_out, y_out, info["size"] = _abi.merge_wavg_regrouped(plan, x_full, info["size"], frames, has_cls=True,
+                                                              ln=(norm.weight, norm.bias, norm.eps), addend=residual,
+                                                              log_size=info["prop_attn"])
     if info["verbose"]:
         print(f"Merged {plan.T} to {plan.T - plan.r} tokens")
     return x_out, y_out

@@ -52,13 +52,9 @@ def _block_forward(self, x, B, T, W):
     rs, metric = self.attn(xs_normed, attn_size)
     rs = self.drop_path(rs)
     cls_new = rs[:, 0, :].reshape(B, T, m).mean(1, keepdim=True)  # class token averaged over frames
-    rs_body = rs.reshape(B, T, 1 + P, m)[:, :, 1:, :].transpose(1, 2)  # '(b t) p -> b p t', still a view
-    if torch.is_grad_enabled() and rs.requires_grad:
-        res = torch.cat((cls_new, rs_body.reshape(B, P * T, m)), 1)
-    else:
-        res = torch.empty_like(x1)  # the second residual, assembled by one strided copy
-        res[:, :1, :] = cls_new
-        res[:, 1:, :].view(B, P, T, m).copy_(rs_body)
+    # the second residual cat(cls_new, rearrange(rs, '(b t) p m -> b (p t) m')) stays where the attention left it: the
+    # fused merge kernel reads it in the grouped layout (GroupedResidual), nothing is permuted unless a slow path asks
+    res = C.GroupedResidual(rs, cls_new, B, T, P)
     # x = cat(cls0, xt) + cat(cls_new, rs); merge per frame; norm2 -- one kernel when the layer merges 16-bit
     # tokens (tome_merge_wavg_regrouped_ln), the reference's steps otherwise
     x, y = C.merge_then_norm_regrouped(
