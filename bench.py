@@ -564,7 +564,11 @@ def worker(args):
         if world == 1 and not args.no_also:
             del model, clips
             torch.cuda.empty_cache()
-            out["also"] = also_workloads(dev, quick=args.also_quick)
+            try:
+                out["also"] = also_workloads(dev, quick=args.also_quick)
+            except Exception as exc:  # the headline line must not be lost to a secondary workload
+                out["also"] = None
+                out["also_error"] = f"{type(exc).__name__}: {exc}"[:500]
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.frames, args.r, args.cpu_clips, args.cpu_iters)
     if world > 1:
