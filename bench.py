@@ -313,8 +313,8 @@ def also_workloads(dev, quick: bool = False):
     plan = [  # (key, family, r values, clips per step)
         ("videomae_b_8x224", "videomae_b_8x224", (16,), 128),
         ("timesformer_divst_8x224", "timesformer_divst_8x224", (8, 16, 32), 64),
-        ("vivit_b_32x224", "vivit_b_32x224", (64,), 16),
-        ("motionformer_224_16x4", "motionformer_224_16x4", (16,), 16),
+        ("vivit_b_32x224", "vivit_b_32x224", (64,), 64),   # (16 -> 64 clips per step: +11 %, GEMM efficiency)
+        ("motionformer_224_16x4", "motionformer_224_16x4", (16,), 64),
     ]
     out = {}
     for key, fam, rs, batch in plan:
