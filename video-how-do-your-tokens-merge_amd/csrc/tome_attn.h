@@ -37,7 +37,10 @@
 // What was tried on this structure and makes no difference (within 1-2 %): a hand-placed issue order (every MFMA
 // followed by the vector work that fits its shadow, sched_barrier fences), sched_group_barrier pipelines, persistent
 // workgroups walking runs of items (-3 %), 5/6/7-wave workgroups to avoid a part-empty last block (-10...-30 %), the
-// full 256-query blocks in one launch and the remaining queries in a second launch of 4-wave workgroups (-3...-12 %).
+// full 256-query blocks in one launch and the remaining queries in a second launch of 4-wave workgroups (-3...-12 %),
+// 64 queries per wave -- four waves per workgroup, one per SIMD with ~500 registers, every K / V fragment serving two
+// query blocks: 647 / 744 / 782 TFLOP/s where this form gives 721 / 818 / 878 (the compiler's schedule at that
+// register count, not the idea, is what loses: the guide's 1.25 PF kernel of that shape is hand-placed assembly).
 // Ablations (results wrong by design, tools/ab_lib.sh): no v_exp +9 %, no barrier 0 %, no V-fragment reads +3 %,
 // no staging at all +11 %; nothing but the MFMAs, row sums and conversions: +26 %.
 // Pitfall met on the way: an `asm("v_add_f32 ...")` reading a v_exp_f32 result gets no hazard padding from hipcc
