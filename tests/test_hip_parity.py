@@ -898,6 +898,33 @@ def test_prop_attention_against_fp32_reference(B, H, N, dtype, tol):
         assert float((out.float() - want).abs().max()) <= tol, mode
 
 
+@pytest.mark.parametrize("dtype,tol", [(torch.bfloat16, 1e-2), (torch.float16, 2e-3)])
+@pytest.mark.parametrize("B,H,P,F", [(2, 3, 196, 8), (1, 2, 36, 4), (1, 12, 64, 8), (2, 1, 100, 3), (1, 2, 5, 2)])
+def test_prop_attention_segments_against_fp32_reference(B, H, P, F, dtype, tol):
+    """tome_prop_attention_segments: every query against F key segments of P keys with a softmax per segment
+    (the per-frame stage of ToMeTrajectoryAttention.forward, tome/patch/motionformer.py:98-121) == the reference's own
+    expression in fp32: q_dot_k regrouped 'b q (f n) -> b q f n', + the flat per-key bias, softmax over n, times v
+    regrouped 'b (f n) d -> b f n d'; q / k / v are views of one qkv buffer behind a class token, as in the patch."""
+    from tome import _abi
+    g = torch.Generator(device=DEV).manual_seed(P * 31 + F)
+    N = 1 + P * F
+    qkv = torch.randn(B, N, 3, H, 64, device=DEV, generator=g).to(dtype)
+    q, k, v = qkv.permute(2, 0, 3, 1, 4)
+    qs, ks, vs = q[:, :, 1:], k[:, :, 1:], v[:, :, 1:]
+    for with_bias in (False, True):
+        lb = None
+        if with_bias:
+            lb = torch.randint(1, 30, (B, P * F), device=DEV, generator=g).float().log()
+        y = _abi.prop_attention_segments(qs, ks, vs, F, 0.125, log_bias=lb)
+        assert y.shape == (B, N - 1, F, H * 64) and y.dtype == dtype
+        logits = (qs.float() @ ks.float().transpose(-1, -2)) * 0.125          # [B, H, S, F*P]
+        if lb is not None:
+            logits = logits + lb[:, None, None, :]
+        w = logits.reshape(B, H, N - 1, F, P).softmax(-1)
+        want = torch.einsum("b h q f n, b h f n d -> b q f h d", w, vs.float().reshape(B, H, F, P, 64))
+        assert float((y.float() - want.reshape(B, N - 1, F, H * 64)).abs().max()) <= tol, with_bias
+
+
 def test_prop_attention_properties():
     """Size-independent properties at full size (ViViT: 3137 tokens): (a) the weights of a query sum to one
     (v = ones -> out = ones); (b) a key of size s counts like s copies of that key (what proportional attention
