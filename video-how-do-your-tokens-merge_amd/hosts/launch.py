@@ -72,6 +72,22 @@ def run(worker: Callable, n_ranks: int, args: Sequence = (), port: Optional[int]
     mp.spawn(_rank_main, args=(worker, n_ranks, "127.0.0.1", port, tuple(args)), nprocs=n_ranks, join=True)
 
 
+class _StdoutToStderr:
+    """File descriptor 1 points at stderr inside the block: gloo announces its connections with printf on stdout,
+    and the drivers' stdout is reserved for the ONE result line."""
+
+    def __enter__(self):
+        import sys
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+        return False
+
+
 def init_process_group(backend: str, device=None) -> None:
     """Join the job's process group (no-op for a single process).  backend "nccl" is RCCL on ROCm."""
     import torch.distributed as dist
@@ -82,7 +98,9 @@ def init_process_group(backend: str, device=None) -> None:
     if backend == "nccl" and device is not None:
         dist.init_process_group(backend="nccl", device_id=device)
     else:
-        dist.init_process_group(backend=backend)
+        with _StdoutToStderr():
+            dist.init_process_group(backend=backend)
+            dist.barrier()  # gloo connects (and reports) on first use
     if dist.get_world_size() != world:
         raise SystemExit(f"process group has {dist.get_world_size()} ranks, environment says {world}")
 
