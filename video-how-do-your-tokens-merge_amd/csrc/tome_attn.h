@@ -465,19 +465,28 @@ __global__ __launch_bounds__(64 * WAVES, 2) void k_prop_attention(AttnArgs a) { 
     // ---- out[b, q, h*64 + d] = O^T[d][q] / l ; register v <-> channel (v&3) + 8*(v>>2) + 4*hf (+32)
     const float l_tot = l_run + __shfl_xor(l_run, 32);
     const float inv = 1.0f / l_tot;
-    if (qrow < a.N) {
-        short *op = reinterpret_cast<short *>(a.out) + b * a.o_sb + (int64_t)qrow * a.o_sn + h * a.o_sh + seg * a.o_seg;
+    // A lane holds channels 8g + 4*hf .. +3 (w0) and 32 + 8g + 4*hf .. +3 (w1) of its query; its partner lane l^32 holds
+    // the other halves.  One v_permlane32_swap per dword hands the lower lane the partner's w0 and the upper lane the
+    // partner's w1, so every lane stores 16 contiguous bytes (channels 8g .. 8g+7, +32 for the upper lanes): four
+    // 16-byte stores per lane instead of eight 8-byte ones.  (All 64 lanes take part in the swaps; only the stores are
+    // predicated.)
+    short *op = reinterpret_cast<short *>(a.out) + b * a.o_sb + (int64_t)(qrow < a.N ? qrow : 0) * a.o_sn + h * a.o_sh +
+                seg * a.o_seg + 32 * hf;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            att_s16x4 w0, w1;
+    for (int g = 0; g < 4; ++g) {
+        att_s16x4 w0, w1;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                w0[e] = att_bits<TX>(o0[4 * g + e] * inv);
-                w1[e] = att_bits<TX>(o1[4 * g + e] * inv);
-            }
-            *reinterpret_cast<att_s16x4 *>(op + 8 * g + 4 * hf) = w0;
-            *reinterpret_cast<att_s16x4 *>(op + 32 + 8 * g + 4 * hf) = w1;
+        for (int e = 0; e < 4; ++e) {
+            w0[e] = att_bits<TX>(o0[4 * g + e] * inv);
+            w1[e] = att_bits<TX>(o1[4 * g + e] * inv);
         }
+        unsigned a2[2], b2[2];
+        __builtin_memcpy(a2, &w0, 8);
+        __builtin_memcpy(b2, &w1, 8);
+        const auto s0w = __builtin_amdgcn_permlane32_swap(a2[0], b2[0], false, false);
+        const auto s1w = __builtin_amdgcn_permlane32_swap(a2[1], b2[1], false, false);
+        const uint4 row16 = uint4{s0w[0], s1w[0], s0w[1], s1w[1]};
+        if (qrow < a.N) *reinterpret_cast<uint4 *>(op + 8 * g) = row16;
     }
 }
 

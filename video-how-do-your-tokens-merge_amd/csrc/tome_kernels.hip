@@ -748,11 +748,12 @@ static int prop_attention_impl(const void *q, const void *k, const void *v, int 
     a.q_sb = q_strides[0]; a.q_sh = q_strides[1]; a.q_sn = q_strides[2];
     a.k_sb = k_strides[0]; a.k_sh = k_strides[1]; a.k_sn = k_strides[2];
     a.v_sb = v_strides[0]; a.v_sh = v_strides[1]; a.v_sn = v_strides[2];
-    if (out_strides) {  // {batch, head, token} element strides of out[b, q, h, 0..63]; rows 8-byte aligned
-        if (out_strides[0] % 4 || out_strides[1] % 4 || out_strides[2] % 4 || ((uintptr_t)out & 7))
-            return fail(TOME_EINVAL, "tome_prop_attention: out rows must be 8-byte aligned");
+    if (out_strides) {  // {batch, head, token} element strides of out[b, q, h, 0..63]; rows 16-byte aligned
+        if (out_strides[0] % 8 || out_strides[1] % 8 || out_strides[2] % 8 || ((uintptr_t)out & 15))
+            return fail(TOME_EINVAL, "tome_prop_attention: out rows must be 16-byte aligned");
         a.o_sb = out_strides[0]; a.o_sh = out_strides[1]; a.o_sn = out_strides[2];
     } else {
+        if ((uintptr_t)out & 15) return fail(TOME_EINVAL, "tome_prop_attention: out must be 16-byte aligned");
         a.o_sb = N * H * D; a.o_sh = D; a.o_sn = H * D;
     }
     a.log_size = log_size; a.ls_sb = log_size_stride;
@@ -760,7 +761,7 @@ static int prop_attention_impl(const void *q, const void *k, const void *v, int 
     a.nseg = (int)nseg;
     a.k_seg = a.v_seg = a.o_seg = a.ls_seg = 0;
     if (seg_strides) {  // {k, v, out, log_size} element offsets from one segment to the next
-        if (seg_strides[0] % 8 || seg_strides[1] % 8 || seg_strides[2] % 4)
+        if (seg_strides[0] % 8 || seg_strides[1] % 8 || seg_strides[2] % 8)
             return fail(TOME_EINVAL, "tome_prop_attention_segments: segment offsets must keep rows 16/8-byte aligned");
         a.k_seg = seg_strides[0]; a.v_seg = seg_strides[1]; a.o_seg = seg_strides[2]; a.ls_seg = seg_strides[3];
     }
