@@ -259,6 +259,12 @@ int tome_unmerge(const void *x, int dtype, int64_t n, int64_t T, int64_t C, int6
                  const int64_t *src_idx, const int64_t *dst_idx, const int64_t *unm_idx, void *out,
                  tome_stream_t stream);
 
+/* tome_gelu_erf  <-  the activation of the MLP the patched block calls between merge and second residual
+ * (`x = x + self.drop_path(self.mlp(self.norm2(x)))`, tome/patch/videomae.py:29, timesformer.py:56,
+ * motionformer.py:29; the models' `act_layer=nn.GELU`): y = x * 0.5 * (1 + erf(x / sqrt(2))) on `elements` 16-bit
+ * values (a multiple of 8), fp32 arithmetic, bit-identical to the framework's kernel.  y may alias x. */
+int tome_gelu_erf(const void *x, int dtype, int64_t elements, void *y, tome_stream_t stream);
+
 /* tome_row_map / tome_source_init  <-  merge_source(merge, x, source=None) (merge.py:372-384) and the drop modes'
  * `drop(eye)` (tome/patch/videomae.py:112-117): the first layer's source matrix.  The reference builds an
  * [n,T,T] identity and merges it with mode "max"; element (o, t) of the result is 1 exactly when token t lands in

@@ -1072,6 +1072,26 @@ def test_prop_attention_running_maximum_moves(growth, dtype, tol):
         assert float((out.float() - want).abs().max()) <= tol
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_gelu_erf_is_the_frameworks_gelu(dtype):
+    """tome_gelu_erf (the MLP's activation inside the patched block) == torch's nn.GELU() bit for bit: same fp32
+    expression, one rounding; every finite 16-bit value is tried, plus a large tensor and the in-place form."""
+    from tome import _abi
+    bits = torch.arange(-32768, 32768, dtype=torch.int32).to(torch.int16).to(DEV)
+    x = bits.view(dtype)
+    x = x[torch.isfinite(x.float())]
+    x = x[: x.numel() // 8 * 8].contiguous()
+    want = torch.nn.functional.gelu(x)
+    assert torch.equal(_abi.gelu_erf(x), want)
+    g = torch.Generator(device=DEV).manual_seed(1)
+    big = (3.0 * torch.randn(64, 197, 3072, device=DEV, generator=g)).to(dtype)
+    want = torch.nn.functional.gelu(big)
+    assert torch.equal(_abi.gelu_erf(big), want)
+    assert torch.equal(_abi.gelu_erf(big.clone(), inplace=True), want)
+    with pytest.raises(_abi.TomeHipError):
+        _abi.gelu_erf(big.float())
+
+
 def test_kernels_are_deterministic():
     """No atomics, no data-dependent reduction order anywhere on the path: the same inputs give the same bits,
     call after call (matching, fused merge + LayerNorm, add + LayerNorm, attention with and without bias)."""

@@ -820,6 +820,22 @@ extern "C" int tome_trajectory_mix(const void *q2, const void *k2, const void *v
     return check_launch("k_trajectory_mix");
 }
 
+extern "C" int tome_gelu_erf(const void *x, int dtype, int64_t elements, void *y, tome_stream_t stream) {
+    if (!x || !y || elements <= 0) return fail(TOME_EINVAL, "tome_gelu_erf: bad shape/pointer");
+    if (dtype != TOME_BF16 && dtype != TOME_F16) return fail(TOME_EINVAL, "tome_gelu_erf: 16-bit tensors only");
+    if (elements % 8 || !aligned16(x) || !aligned16(y))
+        return fail(TOME_EINVAL, "tome_gelu_erf: a multiple of 8 elements in 16-byte aligned buffers required");
+    const int64_t chunks = elements / 8;
+    const int64_t blocks = (chunks + 1023) / 1024;  // 256 threads x 4 chunks
+    if (blocks > 0x7fffffffLL) return fail(TOME_EINVAL, "tome_gelu_erf: too large");
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == TOME_BF16)
+        hipLaunchKernelGGL(k_gelu_erf<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, st, (const bf16_t *)x, (bf16_t *)y, chunks);
+    else
+        hipLaunchKernelGGL(k_gelu_erf<f16_t>, dim3((unsigned)blocks), dim3(256), 0, st, (const f16_t *)x, (f16_t *)y, chunks);
+    return check_launch("k_gelu_erf");
+}
+
 extern "C" int tome_row_map(int64_t n, int64_t T, int64_t r, int distill_token, const int64_t *src_idx,
                             const int64_t *dst_idx, const int64_t *unm_idx, int32_t *row_map, tome_stream_t stream) {
     const int64_t T1 = (T + 1) / 2;

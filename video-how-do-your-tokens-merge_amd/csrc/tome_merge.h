@@ -1054,3 +1054,36 @@ __global__ __launch_bounds__(256) void k_add_ln_regroup(const TX *__restrict__ x
             for (int t = 1; t < F; ++t) st16(yp + (int64_t)t * (1 + P) * cpr, yv);
     }
 }
+
+// k_gelu_erf: the activation between the two GEMMs of the MLP the patched block calls (`self.mlp(self.norm2(x))`,
+// tome/patch/videomae.py:29; nn.GELU() = exact erf form in VideoMAE / TimeSformer / Motionformer):
+//     y = x * 0.5 * (1 + erf(x / sqrt(2)))      fp32 arithmetic on 16-bit values, one rounding -- the expression and
+// operation order of the framework's kernel, so the result is bit-identical to it.  A pure streaming pass: four
+// 16-byte chunks per lane in flight, non-temporal both ways (the [tokens, 4C] activation is 1.2 GB at batch 128).
+template <typename TX>
+__global__ __launch_bounds__(256) void k_gelu_erf(const TX *__restrict__ x, TX *__restrict__ y, int64_t chunks) {
+    constexpr int VEC = 16 / sizeof(TX);
+    constexpr int NIT = 4;
+    const int64_t base = ((int64_t)blockIdx.x * blockDim.x) * NIT + threadIdx.x;
+    uint4 raw[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int64_t q = base + (int64_t)it * blockDim.x;
+        if (q < chunks) raw[it] = ld16(reinterpret_cast<const uint4 *>(x) + q);
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int64_t q = base + (int64_t)it * blockDim.x;
+        if (q >= chunks) continue;
+        Pack<TX, VEC> pk;
+        __builtin_memcpy(&pk, &raw[it], 16);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            const float v = to_f32(pk.e[e]);
+            pk.e[e] = from_f32<TX>(v * 0.5f * (1.0f + erff(v * 0.70710678118654752440f)));
+        }
+        uint4 o;
+        __builtin_memcpy(&o, &pk, 16);
+        st16(reinterpret_cast<uint4 *>(y) + q, o);
+    }
+}

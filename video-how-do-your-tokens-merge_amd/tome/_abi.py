@@ -21,7 +21,7 @@ SYMBOLS = (
     "tome_merge_wavg_regrouped_ln", "tome_add_layernorm", "tome_add_layernorm_regrouped", "tome_prop_attention", "tome_prop_attention_segments", "tome_trajectory_mix", "tome_merge",
     "tome_drop",
     "tome_drop_regrouped",
-    "tome_unmerge", "tome_row_map", "tome_source_init",
+    "tome_unmerge", "tome_row_map", "tome_source_init", "tome_gelu_erf",
     "tome_profile_enable", "tome_profile_read",
 )
 
@@ -96,6 +96,8 @@ def lib() -> ctypes.CDLL:
     L.tome_drop.argtypes = [vp, i32, i64, i64, i64, i64, vp, i32, vp, vp]
     L.tome_unmerge.restype = i32
     L.tome_unmerge.argtypes = [vp, i32, i64, i64, i64, i64, vp, vp, vp, vp, vp]
+    L.tome_gelu_erf.restype = i32
+    L.tome_gelu_erf.argtypes = [vp, i32, i64, vp, vp]
     L.tome_row_map.restype = i32
     L.tome_row_map.argtypes = [i64, i64, i64, i32, vp, vp, vp, vp, vp]
     L.tome_source_init.restype = i32
@@ -704,6 +706,22 @@ def unmerge(plan: MatchPlan, x: torch.Tensor) -> torch.Tensor:
                                 plan.dst_idx.data_ptr(), plan.unm_idx.data_ptr(), out.data_ptr(), _stream(x.device))
     _check(rc, "tome_unmerge")
     return out
+
+
+def gelu_ok(x: torch.Tensor) -> bool:
+    return (x.is_cuda and x.dtype in (torch.bfloat16, torch.float16) and x.is_contiguous() and x.numel() % 8 == 0
+            and x.numel() > 0 and x.data_ptr() % 16 == 0 and not (torch.is_grad_enabled() and x.requires_grad))
+
+
+def gelu_erf(x: torch.Tensor, inplace: bool = False) -> torch.Tensor:
+    """nn.GELU() (exact erf form) of a contiguous 16-bit tensor, bit-identical to torch's, as one streaming pass."""
+    if not gelu_ok(x):
+        raise TomeHipError("gelu_erf: contiguous 16-bit device tensor with a multiple of 8 elements required")
+    y = x if inplace else torch.empty_like(x)
+    with _on_device(x.device):
+        rc = lib().tome_gelu_erf(x.data_ptr(), dtype_code(x, "x"), x.numel(), y.data_ptr(), _stream(x.device))
+    _check(rc, "tome_gelu_erf")
+    return y
 
 
 def source_init(plan: MatchPlan, drop: bool = False) -> torch.Tensor:

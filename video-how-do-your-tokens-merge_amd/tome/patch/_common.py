@@ -20,6 +20,7 @@ _FUSE_LN = os.environ.get("TOME_FUSE_LN", "1") != "0"  # measurement switch: 0 =
 _FUSE_ADD = os.environ.get("TOME_FUSE_ADD", "1") != "0"  # measurement switch: 0 = residual add as its own pass
 _FUSE_NEXT = os.environ.get("TOME_FUSE_NEXT", "1") != "0"  # 0 = second residual and the next block's norm1 separate
 _ATTN_KERNEL = os.environ.get("TOME_ATTN_KERNEL", "1") != "0"  # 0 = the framework's fused attention (+ bias tensor)
+_GELU_KERNEL = os.environ.get("TOME_GELU_KERNEL", "1") != "0"  # 0 = the framework's GELU pass inside the MLP
 
 
 def swizzle(module: torch.nn.Module, tag: str, methods: dict) -> None:
@@ -95,6 +96,23 @@ def attention(q, k, v, size, scale: float, dropout_p: float = 0.0, bias_skip: bo
             bias = log
     out = torch.nn.functional.scaled_dot_product_attention(q, k, v, attn_mask=bias, dropout_p=dropout_p, scale=scale)
     return out.transpose(1, 2).reshape(B, N, H * hd)
+
+
+def run_mlp(mlp, y):
+    """`self.mlp(y)` of the patched block (tome/patch/videomae.py:29).  An MLP of the usual shape -- fc1, exact-erf
+    nn.GELU, fc2, dropout that is the identity in eval -- runs its activation on tome_gelu_erf (same bits as the
+    framework's kernel, non-temporal streaming: 394 -> ~350 us at batch 128); anything else is called as it is."""
+    from .. import _abi
+    act = getattr(mlp, "act", None)
+    fc1, fc2 = getattr(mlp, "fc1", None), getattr(mlp, "fc2", None)
+    if (_GELU_KERNEL and isinstance(act, torch.nn.GELU) and getattr(act, "approximate", "none") == "none"
+            and isinstance(fc1, torch.nn.Linear) and isinstance(fc2, torch.nn.Linear) and not mlp.training
+            and set(dict(mlp.named_children())) <= {"fc1", "act", "fc2", "drop", "drop1", "drop2"}):
+        h = fc1(y)
+        if _abi.gelu_ok(h):
+            return fc2(_abi.gelu_erf(h, inplace=True))
+        return fc2(act(h))
+    return mlp(y)
 
 
 def pick_reduction(mode: str, merge_fn, drop_fn, hybrid_fn):

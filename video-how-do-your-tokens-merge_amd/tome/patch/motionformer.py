@@ -22,7 +22,7 @@ def _block_forward(self, x, seq_len=196, num_frames=8, approx="none", num_landma
     x, y = C.merge_then_norm_regrouped(
         metric, x, info, self.norm2, lambda z: self.reduction_function(metric, z, info, num_frames),
         self.reduction_function is motionformer_merge, num_frames, residual=self.drop_path(attn_out))
-    return C.finish_block(self, x, self.drop_path(self.mlp(y)), info)
+    return C.finish_block(self, x, self.drop_path(C.run_mlp(self.mlp, y)), info)
 
 
 def qkv_attn(q, k, v):

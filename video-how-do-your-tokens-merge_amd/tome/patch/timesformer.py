@@ -61,7 +61,7 @@ def _block_forward(self, x, B, T, W):
         metric, x1, info, self.norm2,
         lambda z: self.reduction_function(metric, z, info, B, T, P), self.reduction_function is timesformer_merge, T,
         residual=res)
-    return C.finish_block(self, x, self.drop_path(self.mlp(y)), info)
+    return C.finish_block(self, x, self.drop_path(C.run_mlp(self.mlp, y)), info)
 
 
 def _attention_forward(self, x, size: torch.Tensor = None):

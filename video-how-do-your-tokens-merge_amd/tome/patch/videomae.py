@@ -26,7 +26,7 @@ def _block_forward(self, x):
     # (tome_merge_wavg_ln with the residual as addend), the three steps of the reference otherwise
     x, y = C.merge_then_norm(metric, x, info, self.norm2, self.reduction_function, videomae_merge,
                              residual=self.drop_path(attn))
-    y = self.mlp(y)
+    y = C.run_mlp(self.mlp, y)
     if self.gamma_2 is not None:
         y = self.gamma_2 * y
     # x + mlp(...), and the next block's norm1 of it in the same pass when that is possible
