@@ -231,6 +231,14 @@ int tome_add_layernorm(const void *x, const void *addend, int dtype, int64_t row
                        const void *ln_weight, const void *ln_bias, float eps, void *x_out, void *y_out,
                        tome_stream_t stream);
 
+/* tome_add_layernorm for rows that come in `groups` groups of `group_rows` whose first row is a class token the
+ * consumer of y does not read: x_out [groups*group_rows, C] as before, y_out [groups*(group_rows-1), C] holds the
+ * LayerNorm of the other rows, compacted.  TimeSformer: `self.temporal_norm1(xt)` with `xt = x[:, 1:, :]`
+ * (tome/patch/timesformer.py:24-26) -- the regrouping '(b p) t m' of y is then a view. */
+int tome_add_layernorm_skip_first(const void *x, const void *addend, int dtype, int64_t groups, int64_t group_rows,
+                                  int64_t C, const void *ln_weight, const void *ln_bias, float eps, void *x_out,
+                                  void *y_out, tome_stream_t stream);
+
 /*
  * tome_add_layernorm_regrouped  <-  the middle of TimeSformer's divided space-time ToMeBlock.forward
  * (tome/patch/timesformer.py:24-38): the temporal attention's residual, the regrouping of the tokens for the

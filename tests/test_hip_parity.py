@@ -670,6 +670,11 @@ def test_add_layernorm(shape, dtype, tol):
     assert torch.equal(xo, x + a)
     ref = torch.nn.functional.layer_norm((x + a).float(), (C,), w.float(), b.float(), 1e-6)
     assert float(((yo.float() - ref).abs() / ref.abs().clamp(min=1.0)).max()) <= tol
+    if len(shape) == 3:
+        # skip_first: the same sums, the LayerNorm output without every clip's first (class) row, compacted -- the
+        # bits of yo[:, 1:] (TimeSformer's temporal_norm1 hand-over, tome/patch/timesformer.py:24-26)
+        xs, ys = _abi.add_layernorm(x, a, w, b, 1e-6, skip_first=True)
+        assert torch.equal(xs, xo) and ys.is_contiguous() and torch.equal(ys, yo[:, 1:])
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.bfloat16, 2 ** -7), (torch.float16, 2 ** -10)])

@@ -396,7 +396,7 @@ static int launch_merge_rows(const void *x, const void *size, int64_t n, int64_t
     const TokLayout lout = lout_p ? *lout_p : contiguous_layout(To, C);
     const bool vec_ok = (C % VEC == 0) && aligned16(x) && aligned16(xout);
     const int64_t cpr = C / VEC;  // 16-byte chunks per row
-    const LnArgs no_ln{nullptr, nullptr, nullptr, 0.0f, nullptr, 0, TokLayout{0, 0, 0, 0, 1}, nullptr};
+    const LnArgs no_ln{nullptr, nullptr, nullptr, 0.0f, nullptr, 0, TokLayout{0, 0, 0, 0, 1}, nullptr, 0};
     if (vec_ok && cpr <= FAST_NIT * WAVE) {
         // rows per wave: measured on MI355X, NIT=6 (four 1536-byte rows per wave for 768-channel bf16 tokens)
         // beats NIT=3 by ~4 %; TOME_MERGE_NIT=3 keeps the other variant reachable for re-measurement
@@ -494,7 +494,7 @@ extern "C" int tome_merge_wavg_ln(const void *x, int x_dtype, const void *size, 
     if (addend && !aligned16(addend)) return fail(TOME_EINVAL, "tome_merge_wavg_ln: addend not 16-byte aligned");
     if (!src_idx || !dst_idx || (!unm_idx && (T + 1) / 2 > r) || !size_out || !y_out || !ln_weight || !ln_bias)
         return fail(TOME_EINVAL, "tome_merge_wavg_ln: null buffer");
-    const LnArgs ln{ln_weight, ln_bias, y_out, eps, addend, 0, TokLayout{0, 0, 0, 0, 1}, nullptr};
+    const LnArgs ln{ln_weight, ln_bias, y_out, eps, addend, 0, TokLayout{0, 0, 0, 0, 1}, nullptr, 0};
     hipStream_t st = (hipStream_t)stream;
 #define WAVGLN(TX, TS)                                                                                         \
     return launch_merge_rows<TX, TS, OP_WAVG>(x, size, n, T, C, r, src_idx, dst_idx, unm_idx, distill_token,   \
@@ -554,7 +554,7 @@ extern "C" int tome_merge_wavg_regrouped_ln(const void *x, int x_dtype, const vo
     if ((addend && !aligned16(addend)) || (cls_addend && !aligned16(cls_addend)))
         return fail(TOME_EINVAL, "tome_merge_wavg_regrouped_ln: addend alignment");
     if (addend_grouped && !addend) return fail(TOME_EINVAL, "tome_merge_wavg_regrouped_ln: addend_grouped without addend");
-    LnArgs ln{ln_weight, ln_bias, y_out, eps, addend, 0, TokLayout{0, 0, 0, 0, 1}, nullptr};
+    LnArgs ln{ln_weight, ln_bias, y_out, eps, addend, 0, TokLayout{0, 0, 0, 0, 1}, nullptr, 0};
     if (addend_grouped) {  // addend [B*F, has_cls + P, C]: group g's token p at (g*(cls+P) + cls + p)*C
         const int64_t cls = has_cls ? 1 : 0;
         ln.a_own = 1;
@@ -565,9 +565,29 @@ extern "C" int tome_merge_wavg_regrouped_ln(const void *x, int x_dtype, const vo
                                      has_cls, src_idx, dst_idx, unm_idx, edge_keep, x_out, size_out, log_size_out, &ln, stream);
 }
 
+static int add_layernorm_impl(const void *x, const void *addend, int dtype, int64_t rows, int64_t C,
+                              const void *ln_weight, const void *ln_bias, float eps, void *x_out, void *y_out,
+                              int64_t y_group, tome_stream_t stream);
+
 extern "C" int tome_add_layernorm(const void *x, const void *addend, int dtype, int64_t rows, int64_t C,
                                   const void *ln_weight, const void *ln_bias, float eps, void *x_out, void *y_out,
                                   tome_stream_t stream) {
+    return add_layernorm_impl(x, addend, dtype, rows, C, ln_weight, ln_bias, eps, x_out, y_out, 0, stream);
+}
+
+extern "C" int tome_add_layernorm_skip_first(const void *x, const void *addend, int dtype, int64_t groups,
+                                             int64_t group_rows, int64_t C, const void *ln_weight,
+                                             const void *ln_bias, float eps, void *x_out, void *y_out,
+                                             tome_stream_t stream) {
+    if (groups <= 0 || group_rows < 2 || group_rows > 0x7fffffffLL)
+        return fail(TOME_EINVAL, "tome_add_layernorm_skip_first: groups of at least two rows required");
+    return add_layernorm_impl(x, addend, dtype, groups * group_rows, C, ln_weight, ln_bias, eps, x_out, y_out, group_rows,
+                              stream);
+}
+
+static int add_layernorm_impl(const void *x, const void *addend, int dtype, int64_t rows, int64_t C,
+                              const void *ln_weight, const void *ln_bias, float eps, void *x_out, void *y_out,
+                              int64_t y_group, tome_stream_t stream) {
     if (!x || !addend || !ln_weight || !ln_bias || !x_out || !y_out || rows <= 0 || C <= 0)
         return fail(TOME_EINVAL, "tome_add_layernorm: bad shape/pointer");
     if (dtype != TOME_BF16 && dtype != TOME_F16) return fail(TOME_EINVAL, "tome_add_layernorm: 16-bit tokens only");
@@ -584,7 +604,7 @@ extern "C" int tome_add_layernorm(const void *x, const void *addend, int dtype, 
     int R = (int)((nit * WAVE) / cpr);
     if (R > FAST_MAXR) R = FAST_MAXR;
     const int64_t waves = (rows + R - 1) / R;
-    const LnArgs ln{ln_weight, ln_bias, y_out, eps, nullptr, 0, TokLayout{0, 0, 0, 0, 1}, nullptr};
+    const LnArgs ln{ln_weight, ln_bias, y_out, eps, nullptr, 0, TokLayout{0, 0, 0, 0, 1}, nullptr, (int)y_group};
     const dim3 grid((unsigned)((waves + 3) / 4));
     hipStream_t st = (hipStream_t)stream;
 #define ADDLN(TX, N)                                                                                              \
@@ -617,7 +637,7 @@ extern "C" int tome_add_layernorm_regrouped(const void *x, const void *addend, i
     if (R > FAST_MAXR) R = FAST_MAXR;
     if (R < 1) return fail(TOME_EINVAL, "tome_add_layernorm_regrouped: row too wide");
     const int64_t waves = (rows + R - 1) / R;
-    const LnArgs ln{ln_weight, ln_bias, y_out, eps, nullptr, 0, TokLayout{0, 0, 0, 0, 1}, nullptr};
+    const LnArgs ln{ln_weight, ln_bias, y_out, eps, nullptr, 0, TokLayout{0, 0, 0, 0, 1}, nullptr, 0};
     const dim3 grid((unsigned)((waves + 3) / 4));
     hipStream_t st = (hipStream_t)stream;
     if (dtype == TOME_BF16)

@@ -43,6 +43,7 @@ struct LnArgs {
     int a_own;
     TokLayout la;
     const void *cls_addend;
+    int y_group;  // k_add_ln_rows only: see there
 };
 
 // 16-byte moves of the streaming kernels (k_merge_rows_fast, k_add_ln_rows, k_add_ln_regroup): tokens are read once
@@ -814,6 +815,10 @@ __global__ __launch_bounds__(256) void k_add_ln_rows(const TX *__restrict__ x, c
                 r3 = 1.0f / __builtin_sqrtf(wave_sum(q3) / fc + ln.eps);
     const TX *lw = reinterpret_cast<const TX *>(ln.weight), *lb = reinterpret_cast<const TX *>(ln.bias);
     uint4 *yo = reinterpret_cast<uint4 *>(reinterpret_cast<TX *>(ln.y) + row0 * C);
+    // y_group > 0: rows come in groups of y_group whose FIRST row (a class token) has no place in y -- y holds the other
+    // y_group - 1 rows of every group, compacted (TimeSformer's temporal_norm1 feeds only the patch tokens,
+    // tome/patch/timesformer.py:24-26, so `xn[:, 1:]` regrouped '(b p) t m' is a view instead of a copy)
+    const int yg = ln.y_group;
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
         const int rr = rowof[it];
@@ -831,7 +836,13 @@ __global__ __launch_bounds__(256) void k_add_ln_rows(const TX *__restrict__ x, c
         for (int e = 0; e < VEC; ++e) pk.e[e] = from_f32<TX>((to_f32(pk.e[e]) - m) * rs * w8[e] + b8[e]);
         uint4 yv;
         __builtin_memcpy(&yv, &pk, 16);
-        st16(yo + q, yv);
+        if (yg > 0) {
+            const int64_t grow = row0 + rr, gb = grow / yg;
+            if (grow - gb * yg == 0) continue;
+            st16(reinterpret_cast<uint4 *>(reinterpret_cast<TX *>(ln.y) + (grow - gb - 1) * C) + cc, yv);
+        } else {
+            st16(yo + q, yv);
+        }
     }
 }
 

@@ -18,7 +18,7 @@ SYMBOLS = (
     "tome_abi_version", "tome_last_error", "tome_effective_r", "tome_match_workspace_bytes", "tome_match",
     "tome_match_keys",
     "tome_match_scores", "tome_edge_keep", "tome_merge_wavg", "tome_merge_wavg_ln", "tome_merge_wavg_regrouped",
-    "tome_merge_wavg_regrouped_ln", "tome_add_layernorm", "tome_add_layernorm_regrouped", "tome_prop_attention", "tome_prop_attention_segments", "tome_trajectory_mix", "tome_merge",
+    "tome_merge_wavg_regrouped_ln", "tome_add_layernorm", "tome_add_layernorm_skip_first", "tome_add_layernorm_regrouped", "tome_prop_attention", "tome_prop_attention_segments", "tome_trajectory_mix", "tome_merge",
     "tome_drop",
     "tome_drop_regrouped",
     "tome_unmerge", "tome_row_map", "tome_source_init", "tome_gelu_erf",
@@ -78,6 +78,8 @@ def lib() -> ctypes.CDLL:
                                                ctypes.c_float, vp, i32, vp, vp, vp, vp, vp, vp]
     L.tome_add_layernorm.restype = i32
     L.tome_add_layernorm.argtypes = [vp, vp, i32, i64, i64, vp, vp, ctypes.c_float, vp, vp, vp]
+    L.tome_add_layernorm_skip_first.restype = i32
+    L.tome_add_layernorm_skip_first.argtypes = [vp, vp, i32, i64, i64, i64, vp, vp, ctypes.c_float, vp, vp, vp]
     L.tome_add_layernorm_regrouped.restype = i32
     L.tome_add_layernorm_regrouped.argtypes = [vp, vp, i32, i64, i64, i64, i64, vp, vp, ctypes.c_float, vp, vp, vp]
     L.tome_merge.restype = i32
@@ -405,8 +407,11 @@ def merge_wavg_ln(plan: MatchPlan, x: torch.Tensor, size: Optional[torch.Tensor]
     return x_out, y_out, s_out
 
 
-def add_layernorm(x: torch.Tensor, addend: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, eps: float):
-    """(x + addend, LayerNorm(x + addend)) in one launch, for 16-bit [..., C] tensors (C <= 1024, C % 8 == 0)."""
+def add_layernorm(x: torch.Tensor, addend: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, eps: float,
+                  skip_first: bool = False):
+    """(x + addend, LayerNorm(x + addend)) in one launch, for 16-bit [..., C] tensors (C <= 1024, C % 8 == 0).
+    skip_first (x [B, N, C]): the LayerNorm output leaves out every clip's first row (the class token) and is
+    [B, N-1, C] -- what TimeSformer's temporal_norm1 consumer reads (`xn[:, 1:]`), as a contiguous tensor."""
     require_device(x, "add_layernorm(x)")
     if addend.shape != x.shape or addend.dtype != x.dtype or addend.device != x.device:
         raise TomeHipError("add_layernorm: addend must match x in shape, dtype and device")
@@ -414,6 +419,16 @@ def add_layernorm(x: torch.Tensor, addend: torch.Tensor, weight: torch.Tensor, b
     addend = addend if addend.is_contiguous() else addend.contiguous()
     C = x.shape[-1]
     x_out = torch.empty_like(x)
+    if skip_first:
+        if x.dim() != 3 or x.shape[1] < 2:
+            raise TomeHipError("add_layernorm(skip_first): x must be [B, N >= 2, C]")
+        y_out = torch.empty((x.shape[0], x.shape[1] - 1, C), dtype=x.dtype, device=x.device)
+        with _on_device(x.device):
+            rc = lib().tome_add_layernorm_skip_first(x.data_ptr(), addend.data_ptr(), dtype_code(x, "x"), x.shape[0],
+                                                     x.shape[1], C, weight.data_ptr(), bias.data_ptr(), float(eps),
+                                                     x_out.data_ptr(), y_out.data_ptr(), _stream(x.device))
+        _check(rc, "tome_add_layernorm_skip_first")
+        return x_out, y_out
     y_out = torch.empty_like(x)
     with _on_device(x.device):
         rc = lib().tome_add_layernorm(x.data_ptr(), addend.data_ptr(), dtype_code(x, "x"), x.numel() // C, C,

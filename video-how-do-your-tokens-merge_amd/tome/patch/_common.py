@@ -21,6 +21,7 @@ _FUSE_ADD = os.environ.get("TOME_FUSE_ADD", "1") != "0"  # measurement switch: 0
 _FUSE_NEXT = os.environ.get("TOME_FUSE_NEXT", "1") != "0"  # 0 = second residual and the next block's norm1 separate
 _ATTN_KERNEL = os.environ.get("TOME_ATTN_KERNEL", "1") != "0"  # 0 = the framework's fused attention (+ bias tensor)
 _GELU_KERNEL = os.environ.get("TOME_GELU_KERNEL", "1") != "0"  # 0 = the framework's GELU pass inside the MLP
+_SKIP_FIRST = os.environ.get("TOME_SKIP_FIRST", "1") != "0"  # the temporal hand-over without the class row
 
 
 def swizzle(module: torch.nn.Module, tag: str, methods: dict) -> None:
@@ -137,25 +138,30 @@ def reduce_merge(metric, x, info, r):
     return x
 
 
-def link_next_norms(blocks, norm_attr: str, tag: str = "ToMeBlock") -> None:
+def link_next_norms(blocks, norm_attr: str, tag: str = "ToMeBlock", skip_first: bool = False) -> None:
     """Tell every patched block which LayerNorm reads its output (the next block's first norm), so the block's
     last residual add can hand that norm's result over (finish_block / first_norm).  Stored without registering
-    the norm as a submodule of the previous block."""
+    the norm as a submodule of the previous block.  skip_first: that norm's consumer reads `norm(x)[:, 1:]` only
+    (TimeSformer's temporal_norm1), so the hand-over leaves the class-token row out."""
     blocks = list(blocks)
     for cur, nxt in zip(blocks, blocks[1:]):
         target = getattr(nxt, norm_attr, None) if has_tag(nxt, tag) and nxt is not cur else None
         object.__setattr__(cur, "_tome_next_norm", target)
+        object.__setattr__(cur, "_tome_next_skip_first", bool(skip_first) and _SKIP_FIRST)
     if blocks:
         object.__setattr__(blocks[-1], "_tome_next_norm", None)
 
 
-def first_norm(block, x, info, norm):
+def first_norm(block, x, info, norm, skip_first: bool = False):
     """norm(x) at the top of a block -- taken from the previous block's fused add+LayerNorm when it left one
-    for exactly this tensor."""
+    for exactly this tensor.  skip_first: returns norm(x)[:, 1:] (contiguous when it comes from the hand-over)."""
     pre = info.pop("_prenorm", None)
     if pre is not None and pre[0] is x and pre[2] is norm:
-        return pre[1]
-    return norm(x)
+        if bool(pre[3]) == bool(skip_first):
+            return pre[1]
+        if skip_first:  # a full hand-over for a reader of the patch rows
+            return pre[1][:, 1:, :]
+    return norm(x)[:, 1:, :] if skip_first else norm(x)
 
 
 def finish_block(block, x, residual, info):
@@ -164,8 +170,9 @@ def finish_block(block, x, residual, info):
     from .. import _abi
     nxt = getattr(block, "_tome_next_norm", None)
     if _FUSE_NEXT and nxt is not None and residual.dtype == x.dtype and _abi.ln_fusable(x, nxt):
-        x, h = _abi.add_layernorm(x, residual, nxt.weight, nxt.bias, nxt.eps)
-        info["_prenorm"] = (x, h, nxt)
+        skip = bool(getattr(block, "_tome_next_skip_first", False)) and x.dim() == 3 and x.shape[1] >= 2
+        x, h = _abi.add_layernorm(x, residual, nxt.weight, nxt.bias, nxt.eps, skip_first=skip)
+        info["_prenorm"] = (x, h, nxt, skip)
         return x
     return x + residual
 

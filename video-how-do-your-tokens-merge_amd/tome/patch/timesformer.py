@@ -22,8 +22,9 @@ def _block_forward(self, x, B, T, W):
     # temporal attention over the T copies of every spatial token
     # temporal_norm1 is per row: taken over the whole token tensor (one extra class row per clip) it can come
     # from the previous block's fused residual + LayerNorm (finish_block below)
-    xn = C.first_norm(self, x, info, self.temporal_norm1)
-    rt = self.drop_path(self.temporal_attn(xn[:, 1:, :].reshape(B * P, T, m))).reshape(B, P * T, m)
+    # (only the patch tokens of it are read: the hand-over leaves the class row out, so the regrouping is a view)
+    xn = C.first_norm(self, x, info, self.temporal_norm1, skip_first=True)
+    rt = self.drop_path(self.temporal_attn(xn.reshape(B * P, T, m))).reshape(B, P * T, m)
     cls0 = x[:, :1, :]
     rt = self.temporal_fc(rt)
     if C._FUSE_NEXT and rt.dtype == x.dtype and _abi.ln_fusable(x, self.norm1):
@@ -142,4 +143,4 @@ def apply_patch(model_wrapper, trace_source: bool = False, prop_attn: bool = Tru
     if getattr(model, "attention_type", "divided_space_time") == "divided_space_time":
         # the first LayerNorm of a divided space-time block is temporal_norm1: the previous block's last residual
         # add hands it over fused (tome_add_layernorm)
-        C.link_next_norms(model.blocks, "temporal_norm1")
+        C.link_next_norms(model.blocks, "temporal_norm1", skip_first=True)
