@@ -129,7 +129,7 @@ def measure_kernels(batch: int, t0: int, r: int, dev, reps: int = 10):
             rc = L.tome_merge_wavg_ln(x.data_ptr(), 1, sp, 1, batch, t, EMBED, re, plan.src_idx.data_ptr(),
                                       plan.dst_idx.data_ptr(), plan.unm_idx.data_ptr(), 0, None, ln_w.data_ptr(),
                                       ln_b.data_ptr(), 1e-6, res.data_ptr(), x_out.data_ptr(), y_out.data_ptr(),
-                                      s_out.data_ptr(), None, st)
+                                      s_out.data_ptr(), None, None, st)
             assert rc == 0
         for _ in range(2):
             launch()

@@ -39,7 +39,7 @@ enum tome_status {
     TOME_ELAUNCH = 3     /* HIP reported a launch error (text in tome_last_error()) */
 };
 
-#define TOME_ABI_VERSION 5
+#define TOME_ABI_VERSION 6
 
 int tome_abi_version(void);
 
@@ -134,12 +134,17 @@ int tome_merge_wavg(const void *x, int x_dtype, const void *size, int size_dtype
  * addend: NULL, or [n,T,C] like x: the tokens that are merged are round_to_dtype(x + addend), i.e. the residual
  * `x = x + attn(norm1(x))` in front of the merge (videomae.py:20, vivit.py:35) is taken while loading and the
  * separate add pass disappears as well.
+ * x_out_bias: NULL, or [C] of the token dtype: x_out is stored as round(x' + x_out_bias) while y_out stays
+ * LayerNorm(x').  For callers that let the MLP's second GEMM accumulate onto x_out in place
+ * (`x = x + self.mlp(self.norm2(x))`, videomae.py:29, as `x_out.addmm_(h, W2^T)`): that GEMM's bias is in the buffer
+ * beforehand, and the block's second residual add is no pass of its own.
  */
 int tome_merge_wavg_ln(const void *x, int x_dtype, const void *size, int size_dtype, int64_t n, int64_t T,
                        int64_t C, int64_t r, const int64_t *src_idx, const int64_t *dst_idx,
                        const int64_t *unm_idx, int distill_token, const uint8_t *edge_keep,
                        const void *ln_weight, const void *ln_bias, float eps, const void *addend, void *x_out,
-                       void *y_out, void *size_out, void *log_size_out, tome_stream_t stream);
+                       void *y_out, void *size_out, void *log_size_out, const void *x_out_bias,
+                       tome_stream_t stream);
 
 /*
  * tome_merge_wavg_regrouped  <-  the rearrange / merge_wavg / rearrange / cat sequence of
@@ -164,13 +169,14 @@ int tome_merge_wavg_regrouped(const void *x, int x_dtype, const void *size, int 
  * in the GROUPED layout [B*F, has_cls + P, C] the spatial attention of TimeSformer leaves it in
  * (tome/patch/timesformer.py:32-52: `res_spatial`, whose '(b t) (h w) m -> b (h w t) m' rearrangement and `cat` with
  * the frame-averaged class token are then not made); its class rows are ignored and the class tokens' addend is
- * cls_addend [B, C] (NULL: none). */
+ * cls_addend [B, C] (NULL: none).  x_out_bias: as in tome_merge_wavg_ln (class-token rows included). */
 int tome_merge_wavg_regrouped_ln(const void *x, int x_dtype, const void *size, int size_dtype, int64_t B,
                                  int64_t F, int64_t P, int64_t C, int64_t r, int has_cls,
                                  const int64_t *src_idx, const int64_t *dst_idx, const int64_t *unm_idx,
                                  const uint8_t *edge_keep, const void *ln_weight, const void *ln_bias, float eps,
                                  const void *addend, int addend_grouped, const void *cls_addend, void *x_out,
-                                 void *y_out, void *size_out, void *log_size_out, tome_stream_t stream);
+                                 void *y_out, void *size_out, void *log_size_out, const void *x_out_bias,
+                                 tome_stream_t stream);
 
 /* tome_drop (below) on the regrouped layout of tome_merge_wavg_regrouped: timesformer_drop / motionformer_drop
  * (tome/patch/timesformer.py:111-131, motionformer.py:172-193) without the permuted copies.
@@ -226,6 +232,8 @@ int tome_trajectory_mix(const void *q2, const void *k2, const void *val, int dty
  *     x = x + self.drop_path(self.mlp(self.norm2(x)))      (tome/patch/videomae.py:29)
  *     ... next ToMeBlock.forward: self.norm1(x)            (tome/patch/videomae.py:19)
  * x_out = round(x + addend), y_out = LayerNorm(x_out), both [rows, C] of `dtype` (16-bit, C <= 1024, C % 8 == 0).
+ * addend NULL: y_out = LayerNorm(x) only -- x already holds the sum (the MLP's GEMM accumulated onto it, see
+ * x_out_bias of tome_merge_wavg_ln); x_out is then ignored and may be NULL.
  */
 int tome_add_layernorm(const void *x, const void *addend, int dtype, int64_t rows, int64_t C,
                        const void *ln_weight, const void *ln_bias, float eps, void *x_out, void *y_out,

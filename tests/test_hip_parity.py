@@ -620,6 +620,10 @@ def test_merge_wavg_ln_fused_residual(n, T, C, r, cls, dtype):
     got = _abi.merge_wavg_ln(merge.plan, x, size, w, b, 1e-6, addend=a)
     for g_, w_ in zip(got, want):
         assert torch.equal(g_, w_)
+    # x_out_bias: x' leaves the kernel as torch's `x' + bias` (one rounding), y and the sizes are those of x' itself
+    ob = dev(0.3 * synth.normal_like((C,), seed + 6), dtype)
+    bx, by, bs = _abi.merge_wavg_ln(merge.plan, x, size, w, b, 1e-6, addend=a, out_bias=ob)
+    assert torch.equal(bx, want[0] + ob) and torch.equal(by, want[1]) and torch.equal(bs, want[2])
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
@@ -654,6 +658,11 @@ def test_merge_wavg_regrouped_ln(B, F, P, C, r, dtype):
                                     cls_addend=res[:, :1].contiguous())
     for g_, w_ in zip(alt, (got_x, got_y, got_s)):
         assert torch.equal(g_, w_)
+    # x_out_bias on the interleaved layout, class-token rows included
+    ob = dev(0.3 * synth.normal_like((C,), seed + 6), dtype)
+    for kw in (dict(addend=res), dict(addend_grouped=grouped, cls_addend=res[:, :1].contiguous())):
+        bx, by, bs = _abi.merge_wavg_regrouped(plan, x_full, size, F, has_cls=True, ln=(w, b, 1e-6), out_bias=ob, **kw)
+        assert torch.equal(bx, got_x + ob) and torch.equal(by, got_y) and torch.equal(bs, got_s)
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.bfloat16, 2 ** -7), (torch.float16, 2 ** -10)])
@@ -675,6 +684,12 @@ def test_add_layernorm(shape, dtype, tol):
         # bits of yo[:, 1:] (TimeSformer's temporal_norm1 hand-over, tome/patch/timesformer.py:24-26)
         xs, ys = _abi.add_layernorm(x, a, w, b, 1e-6, skip_first=True)
         assert torch.equal(xs, xo) and ys.is_contiguous() and torch.equal(ys, yo[:, 1:])
+        _, yn = _abi.add_layernorm(xo, None, w, b, 1e-6, skip_first=True)
+        assert torch.equal(yn, ys)
+    # without an addend: the LayerNorm of x as it is (same bits as the fused form produces for that sum), x untouched
+    keep = xo.clone()
+    xn, yn = _abi.add_layernorm(xo, None, w, b, 1e-6)
+    assert xn is xo and torch.equal(xo, keep) and torch.equal(yn, yo)
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.bfloat16, 2 ** -7), (torch.float16, 2 ** -10)])

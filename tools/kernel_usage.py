@@ -12,11 +12,13 @@ SRC = os.path.join(ROOT, "video-how-do-your-tokens-merge_amd", "csrc", "tome_ker
 
 
 def main():
-    pat = sys.argv[1] if len(sys.argv) > 1 else ""
+    pats = [a for a in sys.argv[1:] if not a.startswith("-")]
+    pat = pats[0] if pats else ""
     with tempfile.TemporaryDirectory() as td:
         out = os.path.join(td, "k.s")
         subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
-                        "-fno-fast-math", "-fhip-fp32-correctly-rounded-divide-sqrt", "-S", "--cuda-device-only", "-o", out, SRC], check=True,
+                        "-fno-fast-math", "-fhip-fp32-correctly-rounded-divide-sqrt", "-S", "--cuda-device-only", "-o", out, SRC]
+                       + [a for a in sys.argv[1:] if a.startswith("-D")], check=True,
                        stderr=subprocess.DEVNULL)
         s = open(out).read()
         if "--keep" in sys.argv:

@@ -6,7 +6,7 @@ import torch
 from tome import _abi, merge as tm
 
 dev = torch.device("cuda", 0)
-B, T, C = 64, 1568, 768
+B, T, C = int(os.environ.get("EXP_B", "64")), 1568, 768
 torch.manual_seed(0)
 x = torch.randn(B, T, C, device=dev, dtype=torch.bfloat16)
 a = torch.randn(B, T, C, device=dev, dtype=torch.bfloat16)
@@ -49,3 +49,17 @@ run("no addend random", 16, addend=None)
 run("no addend sorted", 16, sort_unm=True, addend=None)
 us = timeit(lambda: _abi.add_layernorm(x, a, w, b, 1e-6))
 print(f"add_layernorm same rows {us:7.1f} us {B * T * C * 2 * 4 / us / 1e6:6.2f} TB/s")
+
+ob = torch.randn(C, device=dev, dtype=torch.bfloat16)
+metric = torch.randn(B, T, 64, device=dev)
+plan = tm.bipartite_soft_matching(metric, 16)[0].plan
+for tag, kw in (("out_bias=None", {}), ("out_bias", {"out_bias": ob})):
+    us = timeit(lambda: _abi.merge_wavg_ln(plan, x, size, w, b, 1e-6, addend=a, **kw))
+    print(f"add+merge+ln {tag:14s} {us:7.1f} us")
+us = timeit(lambda: _abi.add_layernorm(x, None, w, b, 1e-6))
+print(f"layernorm only (no addend)  {us:7.1f} us {B * T * C * 2 * 2 / us / 1e6:6.2f} TB/s")
+y = torch.empty_like(x)
+us = timeit(lambda: y.copy_(x))
+print(f"torch copy                  {us:7.1f} us {B * T * C * 2 * 2 / us / 1e6:6.2f} TB/s")
+us = timeit(lambda: torch.add(x, a, out=y))
+print(f"torch add                   {us:7.1f} us {B * T * C * 2 * 3 / us / 1e6:6.2f} TB/s")

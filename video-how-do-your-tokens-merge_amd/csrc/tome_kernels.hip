@@ -396,7 +396,7 @@ static int launch_merge_rows(const void *x, const void *size, int64_t n, int64_t
     const TokLayout lout = lout_p ? *lout_p : contiguous_layout(To, C);
     const bool vec_ok = (C % VEC == 0) && aligned16(x) && aligned16(xout);
     const int64_t cpr = C / VEC;  // 16-byte chunks per row
-    const LnArgs no_ln{nullptr, nullptr, nullptr, 0.0f, nullptr, 0, TokLayout{0, 0, 0, 0, 1}, nullptr, 0};
+    const LnArgs no_ln{nullptr, nullptr, nullptr, 0.0f, nullptr, 0, TokLayout{0, 0, 0, 0, 1}, nullptr, 0, nullptr};
     if (vec_ok && cpr <= FAST_NIT * WAVE) {
         // rows per wave: measured on MI355X, NIT=6 (four 1536-byte rows per wave for 768-channel bf16 tokens)
         // beats NIT=3 by ~4 %; TOME_MERGE_NIT=3 keeps the other variant reachable for re-measurement
@@ -489,12 +489,13 @@ extern "C" int tome_merge_wavg_ln(const void *x, int x_dtype, const void *size, 
                                   const int64_t *unm_idx, int distill_token, const uint8_t *edge_keep,
                                   const void *ln_weight, const void *ln_bias, float eps, const void *addend,
                                   void *x_out, void *y_out, void *size_out, void *log_size_out,
-                                  tome_stream_t stream) {
+                                  const void *x_out_bias, tome_stream_t stream) {
     if (int rc = check_merge_args("tome_merge_wavg_ln", x, n, T, C, r, x_out)) return rc;
     if (addend && !aligned16(addend)) return fail(TOME_EINVAL, "tome_merge_wavg_ln: addend not 16-byte aligned");
+    if (x_out_bias && !aligned16(x_out_bias)) return fail(TOME_EINVAL, "tome_merge_wavg_ln: x_out_bias not 16-byte aligned");
     if (!src_idx || !dst_idx || (!unm_idx && (T + 1) / 2 > r) || !size_out || !y_out || !ln_weight || !ln_bias)
         return fail(TOME_EINVAL, "tome_merge_wavg_ln: null buffer");
-    const LnArgs ln{ln_weight, ln_bias, y_out, eps, addend, 0, TokLayout{0, 0, 0, 0, 1}, nullptr, 0};
+    const LnArgs ln{ln_weight, ln_bias, y_out, eps, addend, 0, TokLayout{0, 0, 0, 0, 1}, nullptr, 0, x_out_bias};
     hipStream_t st = (hipStream_t)stream;
 #define WAVGLN(TX, TS)                                                                                         \
     return launch_merge_rows<TX, TS, OP_WAVG>(x, size, n, T, C, r, src_idx, dst_idx, unm_idx, distill_token,   \
@@ -548,13 +549,15 @@ extern "C" int tome_merge_wavg_regrouped_ln(const void *x, int x_dtype, const vo
                                             const void *ln_bias, float eps, const void *addend,
                                             int addend_grouped, const void *cls_addend, void *x_out,
                                             void *y_out, void *size_out, void *log_size_out,
-                                            tome_stream_t stream) {
+                                            const void *x_out_bias, tome_stream_t stream) {
+    if (x_out_bias && !aligned16(x_out_bias))
+        return fail(TOME_EINVAL, "tome_merge_wavg_regrouped_ln: x_out_bias not 16-byte aligned");
     if (!y_out || !ln_weight || !ln_bias) return fail(TOME_EINVAL, "tome_merge_wavg_regrouped_ln: null buffer");
     if (x_dtype == TOME_F32) return fail(TOME_EINVAL, "tome_merge_wavg_regrouped_ln: 16-bit tokens only");
     if ((addend && !aligned16(addend)) || (cls_addend && !aligned16(cls_addend)))
         return fail(TOME_EINVAL, "tome_merge_wavg_regrouped_ln: addend alignment");
     if (addend_grouped && !addend) return fail(TOME_EINVAL, "tome_merge_wavg_regrouped_ln: addend_grouped without addend");
-    LnArgs ln{ln_weight, ln_bias, y_out, eps, addend, 0, TokLayout{0, 0, 0, 0, 1}, nullptr, 0};
+    LnArgs ln{ln_weight, ln_bias, y_out, eps, addend, 0, TokLayout{0, 0, 0, 0, 1}, nullptr, 0, x_out_bias};
     if (addend_grouped) {  // addend [B*F, has_cls + P, C]: group g's token p at (g*(cls+P) + cls + p)*C
         const int64_t cls = has_cls ? 1 : 0;
         ln.a_own = 1;
@@ -588,12 +591,13 @@ extern "C" int tome_add_layernorm_skip_first(const void *x, const void *addend, 
 static int add_layernorm_impl(const void *x, const void *addend, int dtype, int64_t rows, int64_t C,
                               const void *ln_weight, const void *ln_bias, float eps, void *x_out, void *y_out,
                               int64_t y_group, tome_stream_t stream) {
-    if (!x || !addend || !ln_weight || !ln_bias || !x_out || !y_out || rows <= 0 || C <= 0)
+    // addend == NULL: LayerNorm only (y_out = LN(x)); x_out is then neither read nor written and may be NULL
+    if (!x || !ln_weight || !ln_bias || (addend && !x_out) || !y_out || rows <= 0 || C <= 0)
         return fail(TOME_EINVAL, "tome_add_layernorm: bad shape/pointer");
     if (dtype != TOME_BF16 && dtype != TOME_F16) return fail(TOME_EINVAL, "tome_add_layernorm: 16-bit tokens only");
     const int64_t cpr = C / 8;
-    if (C % 8 || cpr > 2 * WAVE || !aligned16(x) || !aligned16(addend) || !aligned16(x_out) || !aligned16(y_out) ||
-        !aligned16(ln_weight) || !aligned16(ln_bias))
+    if (C % 8 || cpr > 2 * WAVE || !aligned16(x) || !aligned16(addend) || (addend && !aligned16(x_out)) ||
+        !aligned16(y_out) || !aligned16(ln_weight) || !aligned16(ln_bias))
         return fail(TOME_EINVAL, "tome_add_layernorm: C %% 8 == 0, C <= 1024 and 16-byte aligned buffers required");
     static const int nit_env = [] {
         const char *e = getenv("TOME_ADD_LN_NIT");  // 3 chunks per lane: 100.6 us vs 105 us with 6 (batch 64)
@@ -604,7 +608,7 @@ static int add_layernorm_impl(const void *x, const void *addend, int dtype, int6
     int R = (int)((nit * WAVE) / cpr);
     if (R > FAST_MAXR) R = FAST_MAXR;
     const int64_t waves = (rows + R - 1) / R;
-    const LnArgs ln{ln_weight, ln_bias, y_out, eps, nullptr, 0, TokLayout{0, 0, 0, 0, 1}, nullptr, (int)y_group};
+    const LnArgs ln{ln_weight, ln_bias, y_out, eps, nullptr, 0, TokLayout{0, 0, 0, 0, 1}, nullptr, (int)y_group, nullptr};
     const dim3 grid((unsigned)((waves + 3) / 4));
     hipStream_t st = (hipStream_t)stream;
 #define ADDLN(TX, N)                                                                                              \
@@ -637,7 +641,7 @@ extern "C" int tome_add_layernorm_regrouped(const void *x, const void *addend, i
     if (R > FAST_MAXR) R = FAST_MAXR;
     if (R < 1) return fail(TOME_EINVAL, "tome_add_layernorm_regrouped: row too wide");
     const int64_t waves = (rows + R - 1) / R;
-    const LnArgs ln{ln_weight, ln_bias, y_out, eps, nullptr, 0, TokLayout{0, 0, 0, 0, 1}, nullptr, 0};
+    const LnArgs ln{ln_weight, ln_bias, y_out, eps, nullptr, 0, TokLayout{0, 0, 0, 0, 1}, nullptr, 0, nullptr};
     const dim3 grid((unsigned)((waves + 3) / 4));
     hipStream_t st = (hipStream_t)stream;
     if (dtype == TOME_BF16)

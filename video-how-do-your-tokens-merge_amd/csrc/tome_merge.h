@@ -44,7 +44,25 @@ struct LnArgs {
     TokLayout la;
     const void *cls_addend;
     int y_group;  // k_add_ln_rows only: see there
+    // optional [C]: the rows of x_out are stored as round(x' + xbias) while y stays LayerNorm(x').  The caller's next
+    // GEMM accumulates onto x_out in place (`x = x + fc2(...)`, tome/patch/videomae.py:29, as beta = 1 on the residual
+    // buffer), so its bias has to be in the buffer beforehand and the separate residual add disappears.
+    const void *xbias;
 };
+
+// round(v + xbias[c..]) for a 16-byte pack of stored tokens
+template <typename TX, int VEC>
+__device__ __forceinline__ uint4 add_xbias(const uint4 &v, const TX *__restrict__ xb) {
+    Pack<TX, VEC> pk;
+    __builtin_memcpy(&pk, &v, 16);
+    float b8[VEC];
+    load_pack<TX, VEC>(xb, b8);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) pk.e[e] = from_f32<TX>(__fadd_rn(to_f32(pk.e[e]), b8[e]));
+    uint4 o;
+    __builtin_memcpy(&o, &pk, 16);
+    return o;
+}
 
 // 16-byte moves of the streaming kernels (k_merge_rows_fast, k_add_ln_rows, k_add_ln_regroup): tokens are read once
 // and written once, 0.3-1.2 GB per launch against 256 MB of Infinity Cache, so both directions are issued
@@ -244,8 +262,25 @@ __device__ __forceinline__ void merge_dst_row(const TX *__restrict__ xg, const T
                 if (a1) acc1[e] = __fdiv_rn(acc1[e], fc);
             }
         }
-        if (a0) store_pack<TX, VEC>(orow + c0, acc0);
-        if (a1) store_pack<TX, VEC>(orow + c1, acc1);
+        if (LN && ln->xbias) {
+            const TX *xb = reinterpret_cast<const TX *>(ln->xbias);
+            float b8[VEC], o8[VEC];
+            if (a0) {
+                load_pack<TX, VEC>(xb + c0, b8);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) o8[e] = __fadd_rn(to_f32(from_f32<TX>(acc0[e])), b8[e]);
+                store_pack<TX, VEC>(orow + c0, o8);
+            }
+            if (a1) {
+                load_pack<TX, VEC>(xb + c1, b8);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) o8[e] = __fadd_rn(to_f32(from_f32<TX>(acc1[e])), b8[e]);
+                store_pack<TX, VEC>(orow + c1, o8);
+            }
+        } else {
+            if (a0) store_pack<TX, VEC>(orow + c0, acc0);
+            if (a1) store_pack<TX, VEC>(orow + c1, acc1);
+        }
         if (OP == OP_WAVG && lane == 0) store_size<TS>(srow, lrow, ssum);
         if (LN) {
             // LayerNorm of the row as stored (rounded to the token dtype), the whole row is in this wave
@@ -481,8 +516,14 @@ __global__ __launch_bounds__(256) void k_merge_rows_fast(const TX *__restrict__ 
                     __builtin_memcpy(&r0, &p0, 16);
                     __builtin_memcpy(&r1, &p1, 16);
                 }
-                if (a0) dst[c0] = r0;
-                if (a1) dst[c1] = r1;
+                if (ln.xbias) {
+                    const TX *xb = reinterpret_cast<const TX *>(ln.xbias);
+                    if (a0) dst[c0] = add_xbias<TX, VEC>(r0, xb + c0 * VEC);
+                    if (a1) dst[c1] = add_xbias<TX, VEC>(r1, xb + c1 * VEC);
+                } else {
+                    if (a0) dst[c0] = r0;
+                    if (a1) dst[c1] = r1;
+                }
                 float t = 0.0f, u = 0.0f;
 #pragma unroll
                 for (int e = 0; e < VEC; ++e) t += (a0 ? to_f32(p0.e[e]) : 0.0f) + (a1 ? to_f32(p1.e[e]) : 0.0f);
@@ -557,7 +598,9 @@ __global__ __launch_bounds__(256) void k_merge_rows_fast(const TX *__restrict__ 
     // token, B-row number, "something merges into it", size.  Load order matters for latency: the first block
     // of dst_idx and the unm_idx entries go out together; the sizes are requested as soon as the tokens are
     // known but only READ after the token rows' own loads have been issued, so a wave waits for two memory
-    // round trips (index -> rows), not three.
+    // round trips (index -> rows), not three.  (Several R-row slabs per wave behind ONE index round trip were
+    // measured in round 2: no gain for this kernel, a loss for the plain merge -- the kernel is bound by its vector
+    // instructions, not by latency.)
     const int d_first = (OP != OP_DROP && lane < r) ? (int)dstg[lane] : -2;
     int my_tok = 0, my_j = -1;
     float my_s = 1.0f;
@@ -668,8 +711,12 @@ __global__ __launch_bounds__(256) void k_merge_rows_fast(const TX *__restrict__ 
             }
         }
         const int cc = q - rr * cpr;
-        st16(reinterpret_cast<char *>(og + (int64_t)(o0 + rr) * lout.tok_stride) + cc * 16, outv);
-        if (LN) raw[it] = outv;  // keep the stored bits: LayerNorm runs on exactly what was written
+        char *xdst = reinterpret_cast<char *>(og + (int64_t)(o0 + rr) * lout.tok_stride) + cc * 16;
+        if (LN && ln.xbias)
+            st16(xdst, add_xbias<TX, VEC>(outv, reinterpret_cast<const TX *>(ln.xbias) + cc * VEC));
+        else
+            st16(xdst, outv);
+        if (LN) raw[it] = outv;  // keep the merged bits: LayerNorm runs on x' itself (what is written without xbias)
     }
     if (LN) {
         // statistics of the (up to) four rows of this wave, two passes over the registers (mean, then centred
@@ -756,14 +803,18 @@ __global__ __launch_bounds__(256) void k_add_ln_rows(const TX *__restrict__ x, c
     if (row0 >= rows) return;
     const int nrow = (int)((rows - row0) < R ? (rows - row0) : R);
     const int total = nrow * cpr;
-    const uint4 *xs = reinterpret_cast<const uint4 *>(x + row0 * C), *as = reinterpret_cast<const uint4 *>(a + row0 * C);
+    // a == nullptr: LayerNorm only (x is the finished sum -- the caller's GEMM accumulated onto it), nothing is
+    // written to xout
+    const bool add = a != nullptr;
+    const uint4 *xs = reinterpret_cast<const uint4 *>(x + row0 * C),
+                *as = reinterpret_cast<const uint4 *>((add ? a : x) + row0 * C);
     uint4 raw[NIT], rawa[NIT];
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
         const int q = it * WAVE + lane;
         if (q < total) {
             raw[it] = ld16(xs + q);
-            rawa[it] = ld16(as + q);
+            if (add) rawa[it] = ld16(as + q);
         }
     }
     uint4 *xo = reinterpret_cast<uint4 *>(xout + row0 * C);
@@ -775,12 +826,15 @@ __global__ __launch_bounds__(256) void k_add_ln_rows(const TX *__restrict__ x, c
         const int rr = (q >= cpr) + (q >= 2 * cpr) + (q >= 3 * cpr);
         rowof[it] = q < total ? rr : -1;
         if (q >= total) continue;
-        Pack<TX, VEC> px, pa;
-        __builtin_memcpy(&px, &raw[it], 16);
-        __builtin_memcpy(&pa, &rawa[it], 16);
-        const Pack<TX, VEC> ps = add_packs<TX, VEC>(px, pa);
-        __builtin_memcpy(&raw[it], &ps, 16);
-        st16(xo + q, raw[it]);
+        Pack<TX, VEC> ps;
+        __builtin_memcpy(&ps, &raw[it], 16);
+        if (add) {
+            Pack<TX, VEC> pa;
+            __builtin_memcpy(&pa, &rawa[it], 16);
+            ps = add_packs<TX, VEC>(ps, pa);
+            __builtin_memcpy(&raw[it], &ps, 16);
+            st16(xo + q, raw[it]);
+        }
         float t = 0.0f;
 #pragma unroll
         for (int e = 0; e < VEC; ++e) t += to_f32(ps.e[e]);

@@ -25,7 +25,7 @@ SYMBOLS = (
     "tome_profile_enable", "tome_profile_read",
 )
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 DTYPES = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}
 MODES = {"sum": 0, "mean": 1, "amax": 2, "max": 2, "prod": 3, "amin": 4, "min": 4}
 
@@ -69,13 +69,13 @@ def lib() -> ctypes.CDLL:
     L.tome_merge_wavg.argtypes = [vp, i32, vp, i32, i64, i64, i64, i64, vp, vp, vp, i32, vp, vp, vp, vp, vp]
     L.tome_merge_wavg_ln.restype = i32
     L.tome_merge_wavg_ln.argtypes = [vp, i32, vp, i32, i64, i64, i64, i64, vp, vp, vp, i32, vp, vp, vp, ctypes.c_float,
-                                     vp, vp, vp, vp, vp, vp]
+                                     vp, vp, vp, vp, vp, vp, vp]
     L.tome_merge_wavg_regrouped.restype = i32
     L.tome_merge_wavg_regrouped.argtypes = [vp, i32, vp, i32, i64, i64, i64, i64, i64, i32, vp, vp, vp, vp, vp, vp, vp,
                                             vp]
     L.tome_merge_wavg_regrouped_ln.restype = i32
     L.tome_merge_wavg_regrouped_ln.argtypes = [vp, i32, vp, i32, i64, i64, i64, i64, i64, i32, vp, vp, vp, vp, vp, vp,
-                                               ctypes.c_float, vp, i32, vp, vp, vp, vp, vp, vp]
+                                               ctypes.c_float, vp, i32, vp, vp, vp, vp, vp, vp, vp]
     L.tome_add_layernorm.restype = i32
     L.tome_add_layernorm.argtypes = [vp, vp, i32, i64, i64, vp, vp, ctypes.c_float, vp, vp, vp]
     L.tome_add_layernorm_skip_first.restype = i32
@@ -373,12 +373,24 @@ def ln_fusable(x: torch.Tensor, norm) -> bool:
             and not (torch.is_grad_enabled() and (x.requires_grad or norm.weight.requires_grad)))
 
 
+def _out_bias(out_bias, x, C):
+    if out_bias is None:
+        return None
+    if out_bias.numel() != C or out_bias.dtype != x.dtype or out_bias.device != x.device:
+        raise TomeHipError(f"out_bias must hold {C} values of x's dtype on x's device")
+    return out_bias.contiguous()
+
+
 def merge_wavg_ln(plan: MatchPlan, x: torch.Tensor, size: Optional[torch.Tensor], weight: torch.Tensor,
-                  bias: torch.Tensor, eps: float, addend: Optional[torch.Tensor] = None, log_size: bool = False):
+                  bias: torch.Tensor, eps: float, addend: Optional[torch.Tensor] = None, log_size: bool = False,
+                  out_bias: Optional[torch.Tensor] = None):
     """merge_wavg + LayerNorm of the merged tokens in one launch: returns (x_out, y_out, size_out).  With
-    `addend` the merged tokens are `x + addend` (the residual in front of the merge, added while loading)."""
+    `addend` the merged tokens are `x + addend` (the residual in front of the merge, added while loading).
+    out_bias [C]: x_out is stored as x' + out_bias (y_out stays LayerNorm(x')) -- for a caller whose next GEMM
+    accumulates onto x_out in place."""
     x = _prep_x(plan, x, "merge_wavg_ln(x)", plan.T)
     n, T, C = x.shape
+    out_bias = _out_bias(out_bias, x, C)
     if addend is not None:
         if addend.shape != x.shape or addend.dtype != x.dtype or addend.device != x.device:
             raise TomeHipError("merge_wavg_ln: addend must match x in shape, dtype and device")
@@ -402,22 +414,39 @@ def merge_wavg_ln(plan: MatchPlan, x: torch.Tensor, size: Optional[torch.Tensor]
                                       plan.src_idx.data_ptr(), plan.dst_idx.data_ptr(), plan.unm_idx.data_ptr(),
                                       int(plan.distill_token), _ptr(plan.edge_keep), weight.data_ptr(), bias.data_ptr(),
                                       float(eps), _ptr(addend), x_out.data_ptr(), y_out.data_ptr(), s_out.data_ptr(),
-                                      _ptr(log), _stream(x.device))
+                                      _ptr(log), _ptr(out_bias), _stream(x.device))
     _check(rc, "tome_merge_wavg_ln")
     return x_out, y_out, s_out
 
 
-def add_layernorm(x: torch.Tensor, addend: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, eps: float,
+def add_layernorm(x: torch.Tensor, addend: Optional[torch.Tensor], weight: torch.Tensor, bias: torch.Tensor, eps: float,
                   skip_first: bool = False):
     """(x + addend, LayerNorm(x + addend)) in one launch, for 16-bit [..., C] tensors (C <= 1024, C % 8 == 0).
     skip_first (x [B, N, C]): the LayerNorm output leaves out every clip's first row (the class token) and is
     [B, N-1, C] -- what TimeSformer's temporal_norm1 consumer reads (`xn[:, 1:]`), as a contiguous tensor."""
     require_device(x, "add_layernorm(x)")
+    x = x if x.is_contiguous() else x.contiguous()
+    C = x.shape[-1]
+    if addend is None:
+        # LayerNorm only: x holds the finished sum already (returned as it is)
+        if skip_first and (x.dim() != 3 or x.shape[1] < 2):
+            raise TomeHipError("add_layernorm(skip_first): x must be [B, N >= 2, C]")
+        y_out = (torch.empty((x.shape[0], x.shape[1] - 1, C), dtype=x.dtype, device=x.device) if skip_first
+                 else torch.empty_like(x))
+        with _on_device(x.device):
+            if skip_first:
+                rc = lib().tome_add_layernorm_skip_first(x.data_ptr(), None, dtype_code(x, "x"), x.shape[0], x.shape[1],
+                                                         C, weight.data_ptr(), bias.data_ptr(), float(eps), None,
+                                                         y_out.data_ptr(), _stream(x.device))
+            else:
+                rc = lib().tome_add_layernorm(x.data_ptr(), None, dtype_code(x, "x"), x.numel() // C, C,
+                                              weight.data_ptr(), bias.data_ptr(), float(eps), None, y_out.data_ptr(),
+                                              _stream(x.device))
+        _check(rc, "tome_add_layernorm")
+        return x, y_out
     if addend.shape != x.shape or addend.dtype != x.dtype or addend.device != x.device:
         raise TomeHipError("add_layernorm: addend must match x in shape, dtype and device")
-    x = x if x.is_contiguous() else x.contiguous()
     addend = addend if addend.is_contiguous() else addend.contiguous()
-    C = x.shape[-1]
     x_out = torch.empty_like(x)
     if skip_first:
         if x.dim() != 3 or x.shape[1] < 2:
@@ -465,7 +494,7 @@ def add_layernorm_regrouped(x: torch.Tensor, addend: torch.Tensor, frames: int, 
 def merge_wavg_regrouped(plan: MatchPlan, x_full: torch.Tensor, size: Optional[torch.Tensor], frames: int,
                          has_cls: bool = True, ln=None, addend: Optional[torch.Tensor] = None,
                          log_size: bool = False, addend_grouped: Optional[torch.Tensor] = None,
-                         cls_addend: Optional[torch.Tensor] = None):
+                         cls_addend: Optional[torch.Tensor] = None, out_bias: Optional[torch.Tensor] = None):
     """merge_wavg on the interleaved layout of TimeSformer / Motionformer: x_full [B, has_cls + P*F, C] whose
     token has_cls + p*F + f belongs to group b*F + f; returns x_out [B, has_cls + (P-r)*F, C] and size
     [B*F, P-r, 1].  Replaces rearrange -> merge_wavg -> rearrange -> cat (timesformer.py:89-107).
@@ -498,9 +527,10 @@ def merge_wavg_regrouped(plan: MatchPlan, x_full: torch.Tensor, size: Optional[t
     x_out = torch.empty((B, cls + (P - plan.r) * F, C), dtype=x_full.dtype, device=x_full.device)
     s_out = torch.empty((plan.n, P - plan.r, 1), dtype=sdtype, device=x_full.device)
     log = _log_size_like(s_out, log_size)
+    out_bias = _out_bias(out_bias, x_full, C)
     if ln is None:
-        if addend is not None or addend_grouped is not None:
-            raise TomeHipError("merge_wavg_regrouped: addend is only fused together with ln")
+        if addend is not None or addend_grouped is not None or out_bias is not None:
+            raise TomeHipError("merge_wavg_regrouped: addend / out_bias are only fused together with ln")
         with _on_device(x_full.device):
             rc = lib().tome_merge_wavg_regrouped(x_full.data_ptr(), xcode, _ptr(size), DTYPES[sdtype], B, F, P, C,
                                                  plan.r, cls, plan.src_idx.data_ptr(), plan.dst_idx.data_ptr(),
@@ -534,7 +564,7 @@ def merge_wavg_regrouped(plan: MatchPlan, x_full: torch.Tensor, size: Optional[t
                                                 plan.unm_idx.data_ptr(), _ptr(plan.edge_keep), weight.data_ptr(),
                                                 bias.data_ptr(), float(eps), _ptr(addend), grouped,
                                                 _ptr(cls_addend) if grouped else None, x_out.data_ptr(),
-                                                y_out.data_ptr(), s_out.data_ptr(), _ptr(log),
+                                                y_out.data_ptr(), s_out.data_ptr(), _ptr(log), _ptr(out_bias),
                                                 _stream(x_full.device))
     _check(rc, "tome_merge_wavg_regrouped_ln")
     return x_out, y_out, s_out

@@ -21,6 +21,7 @@ _FUSE_ADD = os.environ.get("TOME_FUSE_ADD", "1") != "0"  # measurement switch: 0
 _FUSE_NEXT = os.environ.get("TOME_FUSE_NEXT", "1") != "0"  # 0 = second residual and the next block's norm1 separate
 _ATTN_KERNEL = os.environ.get("TOME_ATTN_KERNEL", "1") != "0"  # 0 = the framework's fused attention (+ bias tensor)
 _GELU_KERNEL = os.environ.get("TOME_GELU_KERNEL", "1") != "0"  # 0 = the framework's GELU pass inside the MLP
+_FUSE_FC2 = os.environ.get("TOME_FUSE_FC2", "1") != "0"  # 0 = the MLP's second GEMM writes its own tensor, then an add
 _SKIP_FIRST = os.environ.get("TOME_SKIP_FIRST", "1") != "0"  # the temporal hand-over without the class row
 
 
@@ -71,6 +72,7 @@ def wrap_model_forward(model_wrapper: torch.nn.Module, blocks_of: Callable) -> N
         self._tome_info["size"] = None
         self._tome_info["source"] = None
         self._tome_info.pop("_prenorm", None)
+        self._tome_info.pop("_folded", None)
         return super(sub, self).forward(*args, **kwdargs)
 
     sub = type("ToMeVisionTransformer", (base,), {"forward": forward, "_tome_tag": "ToMeVisionTransformer"})
@@ -99,21 +101,53 @@ def attention(q, k, v, size, scale: float, dropout_p: float = 0.0, bias_skip: bo
     return out.transpose(1, 2).reshape(B, N, H * hd)
 
 
-def run_mlp(mlp, y):
-    """`self.mlp(y)` of the patched block (tome/patch/videomae.py:29).  An MLP of the usual shape -- fc1, exact-erf
-    nn.GELU, fc2, dropout that is the identity in eval -- runs its activation on tome_gelu_erf (same bits as the
-    framework's kernel, non-temporal streaming: 394 -> ~350 us at batch 128); anything else is called as it is."""
-    from .. import _abi
+def _plain_mlp(mlp) -> bool:
+    """An MLP of the usual shape: fc1, exact-erf nn.GELU, fc2, dropouts that are the identity in eval."""
     act = getattr(mlp, "act", None)
     fc1, fc2 = getattr(mlp, "fc1", None), getattr(mlp, "fc2", None)
-    if (_GELU_KERNEL and isinstance(act, torch.nn.GELU) and getattr(act, "approximate", "none") == "none"
+    return (isinstance(act, torch.nn.GELU) and getattr(act, "approximate", "none") == "none"
             and isinstance(fc1, torch.nn.Linear) and isinstance(fc2, torch.nn.Linear) and not mlp.training
-            and set(dict(mlp.named_children())) <= {"fc1", "act", "fc2", "drop", "drop1", "drop2"}):
-        h = fc1(y)
-        if _abi.gelu_ok(h):
-            return fc2(_abi.gelu_erf(h, inplace=True))
-        return fc2(act(h))
+            and set(dict(mlp.named_children())) <= {"fc1", "act", "fc2", "drop", "drop1", "drop2"})
+
+
+def mlp_hidden(mlp, y):
+    """fc1 and the activation of a plain MLP: the tensor its fc2 reads.  The activation runs on tome_gelu_erf (same
+    bits as the framework's kernel, non-temporal streaming: 394 -> ~350 us at batch 128)."""
+    from .. import _abi
+    h = mlp.fc1(y)
+    if _GELU_KERNEL and _abi.gelu_ok(h):
+        return _abi.gelu_erf(h, inplace=True)
+    return mlp.act(h)
+
+
+def run_mlp(mlp, y):
+    """`self.mlp(y)` of the patched block (tome/patch/videomae.py:29); anything but a plain MLP is called as it is."""
+    if _plain_mlp(mlp):
+        return mlp.fc2(mlp_hidden(mlp, y))
     return mlp(y)
+
+
+def foldable(linear, eval_mode: bool = True):
+    """`linear` when the block's last step `x = x + linear(h)` may run as ONE GEMM that accumulates onto the residual
+    stream in place (`x.addmm_(h, Wᵀ)`, finish_linear) -- which needs the bias in the stream beforehand
+    (merge_then_norm's `fold`, the merge kernel's x_out_bias); None when it may not."""
+    if (_FUSE_FC2 and _FUSE_NEXT and eval_mode and isinstance(linear, torch.nn.Linear) and linear.bias is not None
+            and not (torch.is_grad_enabled() and linear.weight.requires_grad)):
+        return linear
+    return None
+
+
+def mlp_residual(block, mlp, x, y, info, scale=None, drop_path=None):
+    """`x + drop_path(scale * mlp(y))` at the end of a patched block (tome/patch/videomae.py:28-29,
+    timesformer.py:57, motionformer.py:30), with the next block's first norm handed over (finish_block)."""
+    if _plain_mlp(mlp) and scale is None and (drop_path is None or not block.training):
+        return finish_linear(block, x, mlp_hidden(mlp, y), mlp.fc2, info)
+    if info.get("_folded") is not None and info["_folded"][0] is x:
+        raise RuntimeError("the residual stream carries a folded bias, but the block's MLP is not the one it was folded for")
+    y = run_mlp(mlp, y)
+    if scale is not None:
+        y = scale * y
+    return finish_block(block, x, y if drop_path is None else drop_path(y), info)
 
 
 def pick_reduction(mode: str, merge_fn, drop_fn, hybrid_fn):
@@ -177,10 +211,31 @@ def finish_block(block, x, residual, info):
     return x + residual
 
 
-def merge_then_norm(metric, x, info, norm, reduction_function, plain_merge_fn, residual=None):
+def finish_linear(block, x, h, linear, info):
+    """`x + linear(h)` at the end of a block.  When the merge kernel has put linear's bias into x already (`fold`),
+    the GEMM accumulates onto x in place (beta = 1: no tensor for the GEMM's result, no add pass) and the next block's
+    first LayerNorm reads the finished sum once (tome_add_layernorm without addend); otherwise finish_block."""
+    from .. import _abi
+    folded = info.pop("_folded", None)
+    if folded is None or folded[0] is not x:
+        return finish_block(block, x, linear(h), info)
+    if folded[1] is not linear:
+        raise RuntimeError("the residual stream carries the bias of another Linear than the one that finishes the block")
+    x.view(-1, x.shape[-1]).addmm_(h.view(-1, h.shape[-1]), linear.weight.t())
+    nxt = getattr(block, "_tome_next_norm", None)
+    if nxt is not None and _abi.ln_fusable(x, nxt):
+        skip = bool(getattr(block, "_tome_next_skip_first", False)) and x.dim() == 3 and x.shape[1] >= 2
+        _, hn = _abi.add_layernorm(x, None, nxt.weight, nxt.bias, nxt.eps, skip_first=skip)
+        info["_prenorm"] = (x, hn, nxt, skip)
+    return x
+
+
+def merge_then_norm(metric, x, info, norm, reduction_function, plain_merge_fn, residual=None, fold=None):
     """The block steps `[x = x + residual;] x = reduction_function(metric, x, info); y = norm(x)` with the
     residual add and the LayerNorm fused into the merge kernel (tome_merge_wavg_ln) when this layer merges in
-    plain 'merge' mode on 16-bit tokens; returns (x, y).  Anything else runs the steps as the reference does."""
+    plain 'merge' mode on 16-bit tokens; returns (x, y).  Anything else runs the steps as the reference does.
+    fold: the Linear that finishes the block (`foldable`); when the fused kernel runs, x comes back with that bias
+    added (y is the norm of x without it) and info["_folded"] says so for finish_linear."""
     from .. import _abi
     from ..merge import do_nothing
     r_list = info["r"]
@@ -202,8 +257,12 @@ def merge_then_norm(metric, x, info, norm, reduction_function, plain_merge_fn, r
         if info["trace_source"]:
             info["source"] = merge_source(merge, x, info["source"])
         before = x.size(1)
+        fold = fold if (fold is not None and fold.bias.dtype == x.dtype and fold.bias.numel() == x.shape[-1]) else None
         x, y, info["size"] = _abi.merge_wavg_ln(merge.plan, x, info["size"], norm.weight, norm.bias, norm.eps,
-                                                addend=residual, log_size=info["prop_attn"])
+                                                addend=residual, log_size=info["prop_attn"],
+                                                out_bias=None if fold is None else fold.bias)
+        if fold is not None:
+            info["_folded"] = (x, fold)
         if info["verbose"]:
             print(f"Merged {before} to {x.size(1)} tokens")
         return x, y
@@ -257,7 +316,7 @@ class GroupedResidual:
 
 
 def merge_then_norm_regrouped(metric, x_full, info, norm, unfused_reduce, is_plain_merge: bool, frames: int,
-                              residual=None):
+                              residual=None, fold=None):
     """merge_then_norm for the interleaved layouts (TimeSformer '(p t)', Motionformer '(s f)'): x_full is
     [B, 1 + P*F, C]; `unfused_reduce(x)` is the model's own reduction step (it pops r itself).  `residual`: a tensor
     in x's layout, or a GroupedResidual."""
@@ -282,14 +341,19 @@ def merge_then_norm_regrouped(metric, x_full, info, norm, unfused_reduce, is_pla
     merge, _ = bipartite_soft_matching(metric, r, info["class_token"], info["distill_token"], info["mode"])
     assert merge is not do_nothing
     plan = merge.plan
+    fold = fold if (fold is not None and fold.bias.dtype == x_full.dtype
+                    and fold.bias.numel() == x_full.shape[-1]) else None
+    out_bias = None if fold is None else fold.bias
     if grouped is not None:
         x_out, y_out, info["size"] = _abi.merge_wavg_regrouped(
             plan, x_full, info["size"], frames, has_cls=True, ln=(norm.weight, norm.bias, norm.eps),
-            addend_grouped=grouped.rs, cls_addend=grouped.cls_new, log_size=info["prop_attn"])
+            addend_grouped=grouped.rs, cls_addend=grouped.cls_new, log_size=info["prop_attn"], out_bias=out_bias)
     else:
         x_out, y_out, info["size"] = _abi.merge_wavg_regrouped(plan, x_full, info["size"], frames, has_cls=True,
                                                               ln=(norm.weight, norm.bias, norm.eps), addend=residual,
-                                                              log_size=info["prop_attn"])
+                                                              log_size=info["prop_attn"], out_bias=out_bias)
+    if fold is not None:
+        info["_folded"] = (x_out, fold)
     if info["verbose"]:
         print(f"Merged {plan.T} to {plan.T - plan.r} tokens")
     return x_out, y_out

@@ -21,8 +21,9 @@ def _block_forward(self, x, seq_len=196, num_frames=8, approx="none", num_landma
     # x = x + attn; merge per group; norm2 -- one kernel when the layer merges 16-bit tokens
     x, y = C.merge_then_norm_regrouped(
         metric, x, info, self.norm2, lambda z: self.reduction_function(metric, z, info, num_frames),
-        self.reduction_function is motionformer_merge, num_frames, residual=self.drop_path(attn_out))
-    return C.finish_block(self, x, self.drop_path(C.run_mlp(self.mlp, y)), info)
+        self.reduction_function is motionformer_merge, num_frames, residual=self.drop_path(attn_out),
+        fold=C.foldable(self.mlp.fc2, not self.training) if C._plain_mlp(self.mlp) else None)
+    return C.mlp_residual(self, self.mlp, x, y, info, drop_path=self.drop_path)
 
 
 def qkv_attn(q, k, v):

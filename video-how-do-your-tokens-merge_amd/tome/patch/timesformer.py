@@ -61,8 +61,8 @@ def _block_forward(self, x, B, T, W):
     x, y = C.merge_then_norm_regrouped(
         metric, x1, info, self.norm2,
         lambda z: self.reduction_function(metric, z, info, B, T, P), self.reduction_function is timesformer_merge, T,
-        residual=res)
-    return C.finish_block(self, x, self.drop_path(C.run_mlp(self.mlp, y)), info)
+        residual=res, fold=C.foldable(self.mlp.fc2, not self.training) if C._plain_mlp(self.mlp) else None)
+    return C.mlp_residual(self, self.mlp, x, y, info, drop_path=self.drop_path)
 
 
 def _attention_forward(self, x, size: torch.Tensor = None):

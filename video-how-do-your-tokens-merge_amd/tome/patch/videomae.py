@@ -24,13 +24,12 @@ def _block_forward(self, x):
         attn = self.gamma_1 * attn
     # x = x + attn; x = merge(x); y = norm2(x) -- one kernel when the layer merges 16-bit tokens
     # (tome_merge_wavg_ln with the residual as addend), the three steps of the reference otherwise
+    # (fold: x comes back with fc2's bias in it when `x + mlp(...)` below can be fc2's GEMM accumulating onto x)
+    fold = C.foldable(self.mlp.fc2, not self.training) if (self.gamma_2 is None and C._plain_mlp(self.mlp)) else None
     x, y = C.merge_then_norm(metric, x, info, self.norm2, self.reduction_function, videomae_merge,
-                             residual=self.drop_path(attn))
-    y = C.run_mlp(self.mlp, y)
-    if self.gamma_2 is not None:
-        y = self.gamma_2 * y
-    # x + mlp(...), and the next block's norm1 of it in the same pass when that is possible
-    return C.finish_block(self, x, self.drop_path(y), info)
+                             residual=self.drop_path(attn), fold=fold)
+    # x + mlp(...), and the next block's norm1 of it handed over when that is possible
+    return C.mlp_residual(self, self.mlp, x, y, info, scale=self.gamma_2, drop_path=self.drop_path)
 
 
 def _duplicate_block_forward(self, x):

@@ -23,12 +23,17 @@ def _layer_forward(self, hidden_states, head_mask=None, output_attentions=False)
     attention_output, metric, rest = outs[0], outs[1], outs[2:]
     # first residual, merge, layernorm_after -- one kernel when the layer merges 16-bit tokens
     # (tome_merge_wavg_ln with the attention output as addend), the three steps of the reference otherwise
+    # VivitOutput = dense -> dropout -> + hidden_states: in eval that is one GEMM accumulating onto hidden_states
+    # (finish_linear; its bias folded in by the merge kernel), the next layer's layernorm_before handed over
+    eval_mode = not self.training
     hidden_states, normed = C.merge_then_norm(metric, hidden_states, info, self.layernorm_after,
-                                              self.reduction_function, vivit_merge, residual=attention_output)
+                                              self.reduction_function, vivit_merge, residual=attention_output,
+                                              fold=C.foldable(self.output.dense, eval_mode))
     layer_output = self.intermediate(normed)
-    # VivitOutput = dense -> dropout -> + hidden_states; the add is done by finish_block so that the next layer's
-    # layernorm_before can come out of the same pass
-    layer_output = C.finish_block(self, hidden_states, self.output.dropout(self.output.dense(layer_output)), info)
+    if eval_mode:
+        layer_output = C.finish_linear(self, hidden_states, layer_output, self.output.dense, info)
+    else:
+        layer_output = C.finish_block(self, hidden_states, self.output.dropout(self.output.dense(layer_output)), info)
     return (layer_output,) + rest
 
 
