@@ -415,8 +415,13 @@ static int launch_merge_rows(const void *x, const void *size, int64_t n, int64_t
         const int nit = (cpr <= 3 * WAVE) ? (ln_p ? (nit_ln ? nit_ln : (ln_p->addend ? 3 : 6)) : nit_pref) : FAST_NIT;
         int R = (int)((nit * WAVE) / cpr);
         if (R > FAST_MAXR) R = FAST_MAXR;
-        const int64_t waves = n * ((To + R - 1) / R) + (OP == OP_DROP ? 0 : n * r) + cls_rows;
-        const dim3 grid((unsigned)((waves + 3) / 4));
+        // grid.x = the blocks of one group (streaming waves, then the edge waves), (y, z) = group (+ rows of blocks
+        // for the class tokens behind them)
+        const int64_t bpg = ((To + R - 1) / R + (OP == OP_DROP ? 0 : r) + 3) / 4;
+        const int64_t ny = n + (cls_rows ? (cls_rows + 4 * bpg - 1) / (4 * bpg) : 0);
+        const int64_t gy = ny < 65535 ? ny : 65535, gz = (ny + gy - 1) / gy;
+        if (gz > 65535) return fail(TOME_EINVAL, "merge: too many groups (%lld)", (long long)n);
+        const dim3 grid((unsigned)bpg, (unsigned)gy, (unsigned)gz);
         if (ln_p) {
             if (OP != OP_WAVG || sizeof(TX) != 2 || cpr > 2 * WAVE || !aligned16(ln_p->y) || !aligned16(ln_p->weight) ||
                 !aligned16(ln_p->bias))
@@ -424,20 +429,20 @@ static int launch_merge_rows(const void *x, const void *size, int64_t n, int64_t
             if constexpr (OP == OP_WAVG && sizeof(TX) == 2) {
                 if (nit == 3)
                     hipLaunchKernelGGL((k_merge_rows_fast<TX, TS, OP, 3, true>), grid, dim3(256), 0, st, (const TX *)x,
-                                       (const TS *)size, (int)n, (int)T, (int)C, (int)r, R, (int)cpr, src, dst, unm,
+                                       (const TS *)size, (int)n, (int)T, (int)C, (int)r, R, (int)cpr, (int)((To + R - 1) / R), src, dst, unm,
                                        distill, keep, (TX *)xout, (TS *)sout, lin, lout, cls_rows, *ln_p, (TS *)lsout);
                 else
                     hipLaunchKernelGGL((k_merge_rows_fast<TX, TS, OP, 6, true>), grid, dim3(256), 0, st, (const TX *)x,
-                                       (const TS *)size, (int)n, (int)T, (int)C, (int)r, R, (int)cpr, src, dst, unm,
+                                       (const TS *)size, (int)n, (int)T, (int)C, (int)r, R, (int)cpr, (int)((To + R - 1) / R), src, dst, unm,
                                        distill, keep, (TX *)xout, (TS *)sout, lin, lout, cls_rows, *ln_p, (TS *)lsout);
             }
         } else if (nit == 3)
             hipLaunchKernelGGL((k_merge_rows_fast<TX, TS, OP, 3>), grid, dim3(256), 0, st, (const TX *)x,
-                               (const TS *)size, (int)n, (int)T, (int)C, (int)r, R, (int)cpr, src, dst, unm, distill,
+                               (const TS *)size, (int)n, (int)T, (int)C, (int)r, R, (int)cpr, (int)((To + R - 1) / R), src, dst, unm, distill,
                                keep, (TX *)xout, (TS *)sout, lin, lout, cls_rows, no_ln, (TS *)lsout);
         else
             hipLaunchKernelGGL((k_merge_rows_fast<TX, TS, OP, 6>), grid, dim3(256), 0, st, (const TX *)x,
-                               (const TS *)size, (int)n, (int)T, (int)C, (int)r, R, (int)cpr, src, dst, unm, distill,
+                               (const TS *)size, (int)n, (int)T, (int)C, (int)r, R, (int)cpr, (int)((To + R - 1) / R), src, dst, unm, distill,
                                keep, (TX *)xout, (TS *)sout, lin, lout, cls_rows, no_ln, (TS *)lsout);
         return check_launch("k_merge_rows_fast");
     }

@@ -24,6 +24,7 @@ struct TokLayout {
 };
 
 template <typename TX> __device__ __forceinline__ TX *group_ptr(TX *p, const TokLayout &L, int g) {
+    if (L.inner == 1) return p + L.base + (int64_t)g * L.outer_stride;  // (no integer division on the plain layout)
     return p + L.base + (int64_t)(g / L.inner) * L.outer_stride + (int64_t)(g % L.inner) * L.inner_stride;
 }
 
@@ -113,6 +114,152 @@ __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
     return v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm tail of the streaming kernels (k_merge_rows_fast, k_add_ln_rows, k_add_ln_regroup).  These kernels sit at
+// the vector-issue limit of the SIMDs, not only at the HBM limit (measured in round 2: adding ~75 vector instructions
+// per lane cost the merge kernel 6 %; occupancy and index prefetch changed nothing), so the tail is written for few
+// instructions:
+//   * the sum of a 16-byte chunk by dot products with a vector of ones (v_dot2c_f32_bf16 / _f16: two elements per
+//     instruction, no unpacking);
+//   * wave totals by a DPP scan (row_shr 1/2/4/8, row_bcast 15/31) read back from lane 63 as a wave-uniform scalar,
+//     instead of six ds_bpermute round trips per total -- and only for the rows the wave really holds (R of 4);
+//   * the centred values d = x - mean kept in registers between the variance pass and the output pass;
+//   * y = d * (rstd * w) + b as one multiply and one fma per element; 1/C as a multiplication, rstd by v_rsq_f32.
+// Two passes as before (mean, then centred variance): a row far from zero keeps its variance.
+// ------------------------------------------------------------------------------------------------
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ float dpp_add(float v) {
+    const int t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, false);
+    return v + __int_as_float(t);
+}
+__device__ __forceinline__ float wave_total(float v) {  // sum over the 64 lanes, wave-uniform
+    v = dpp_add<0x111, 0xf>(v);  // row_shr:1
+    v = dpp_add<0x112, 0xf>(v);  // row_shr:2
+    v = dpp_add<0x114, 0xf>(v);  // row_shr:4
+    v = dpp_add<0x118, 0xf>(v);  // row_shr:8  -> lane 15 of every row of 16 holds the row's total
+    v = dpp_add<0x142, 0xa>(v);  // row_bcast:15 into rows 1 and 3
+    v = dpp_add<0x143, 0xc>(v);  // row_bcast:31 into rows 2 and 3 -> lane 63 holds the total
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
+typedef __bf16 dot_bf16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 dot_f16x2 __attribute__((ext_vector_type(2)));
+template <typename TX> __device__ __forceinline__ float chunk_sum(const uint4 &v);
+template <> __device__ __forceinline__ float chunk_sum<bf16_t>(const uint4 &v) {
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w}, ones = 0x3f803f80u;
+    dot_bf16x2 o, p;
+    __builtin_memcpy(&o, &ones, 4);
+    float t = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        __builtin_memcpy(&p, &w[i], 4);
+        t = __builtin_amdgcn_fdot2_f32_bf16(p, o, t, false);
+    }
+    return t;
+}
+template <> __device__ __forceinline__ float chunk_sum<f16_t>(const uint4 &v) {
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w}, ones = 0x3c003c00u;
+    dot_f16x2 o, p;
+    __builtin_memcpy(&o, &ones, 4);
+    float t = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        __builtin_memcpy(&p, &w[i], 4);
+        t = __builtin_amdgcn_fdot2(p, o, t, false);
+    }
+    return t;
+}
+
+__device__ __forceinline__ float pick4(int rr, float a0, float a1, float a2, float a3, int R) {
+    float v = a0;
+    if (R > 1) v = rr == 1 ? a1 : v;
+    if (R > 2) {
+        v = rr == 2 ? a2 : v;
+        v = rr == 3 ? a3 : v;
+    }
+    return v;
+}
+
+// raw[it]: the stored bits of chunk `it` of this lane (16-bit tokens, 8 per chunk), rowof[it] its row 0..R-1 or -1;
+// store_y(it, rr, cc, bits) writes one normalised chunk (cc = 16-byte column of the chunk in its row).
+template <typename TX, int NIT, typename StoreY>
+__device__ __forceinline__ void ln_rows(const uint4 (&raw)[NIT], const int (&rowof)[NIT], int R, int cpr, int C,
+                                        float eps, const TX *__restrict__ lw, const TX *__restrict__ lb, int lane,
+                                        StoreY store_y) {
+    constexpr int VEC = 8;
+    const float inv_c = __builtin_amdgcn_rcpf((float)C);
+    // weight and bias chunks of every chunk column this lane holds: requested now, used after the two reductions
+    uint4 wraw[NIT], braw[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int rr = rowof[it];
+        const int cc = rr < 0 ? 0 : it * WAVE + lane - rr * cpr;
+        wraw[it] = *(reinterpret_cast<const uint4 *>(lw) + cc);
+        braw[it] = *(reinterpret_cast<const uint4 *>(lb) + cc);
+    }
+    float p0 = 0.0f, p1 = 0.0f, p2 = 0.0f, p3 = 0.0f;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int rr = rowof[it];
+        const float t = rr >= 0 ? chunk_sum<TX>(raw[it]) : 0.0f;
+        p0 += rr == 0 ? t : 0.0f;
+        if (R > 1) p1 += rr == 1 ? t : 0.0f;
+        if (R > 2) {
+            p2 += rr == 2 ? t : 0.0f;
+            p3 += rr == 3 ? t : 0.0f;
+        }
+    }
+    float m0 = wave_total(p0) * inv_c, m1 = 0.0f, m2 = 0.0f, m3 = 0.0f;
+    if (R > 1) m1 = wave_total(p1) * inv_c;
+    if (R > 2) {
+        m2 = wave_total(p2) * inv_c;
+        m3 = wave_total(p3) * inv_c;
+    }
+    float d[NIT][VEC];
+    p0 = p1 = p2 = p3 = 0.0f;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int rr = rowof[it];
+        const float m = pick4(rr, m0, m1, m2, m3, R);
+        Pack<TX, VEC> pk;
+        __builtin_memcpy(&pk, &raw[it], 16);
+        float u = 0.0f;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            d[it][e] = to_f32(pk.e[e]) - m;
+            u = __fmaf_rn(d[it][e], d[it][e], u);
+        }
+        u = rr >= 0 ? u : 0.0f;
+        p0 += rr == 0 ? u : 0.0f;
+        if (R > 1) p1 += rr == 1 ? u : 0.0f;
+        if (R > 2) {
+            p2 += rr == 2 ? u : 0.0f;
+            p3 += rr == 3 ? u : 0.0f;
+        }
+    }
+    float r0 = __builtin_amdgcn_rsqf(wave_total(p0) * inv_c + eps), r1 = 0.0f, r2 = 0.0f, r3 = 0.0f;
+    if (R > 1) r1 = __builtin_amdgcn_rsqf(wave_total(p1) * inv_c + eps);
+    if (R > 2) {
+        r2 = __builtin_amdgcn_rsqf(wave_total(p2) * inv_c + eps);
+        r3 = __builtin_amdgcn_rsqf(wave_total(p3) * inv_c + eps);
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int rr = rowof[it];
+        if (rr < 0) continue;
+        const int cc = it * WAVE + lane - rr * cpr;
+        const float rs = pick4(rr, r0, r1, r2, r3, R);
+        Pack<TX, VEC> pw, pb, pk;
+        __builtin_memcpy(&pw, &wraw[it], 16);
+        __builtin_memcpy(&pb, &braw[it], 16);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e)
+            pk.e[e] = from_f32<TX>(__fmaf_rn(d[it][e], to_f32(pw.e[e]) * rs, to_f32(pb.e[e])));
+        uint4 yv;
+        __builtin_memcpy(&yv, &pk, 16);
+        store_y(it, rr, cc, yv);
+    }
 }
 
 // One destination row (odd token 2j+1 plus every source merged into it), whole wave, contract order:
@@ -474,7 +621,7 @@ __global__ __launch_bounds__(256) void k_merge_rows(const TX *__restrict__ x, co
 template <typename TX, typename TS, int OP, int NIT, bool LN = false>
 __global__ __launch_bounds__(256) void k_merge_rows_fast(const TX *__restrict__ x, const TS *__restrict__ size,
                                                          int n, int T_, int C, int r, int R, int cpr,
-                                                         const int64_t *__restrict__ src_idx,
+                                                         int rg_per_group, const int64_t *__restrict__ src_idx,
                                                          const int64_t *__restrict__ dst_idx,
                                                          const int64_t *__restrict__ unm_idx, int distill,
                                                          const uint8_t *__restrict__ keep, TX *__restrict__ xout,
@@ -483,13 +630,17 @@ __global__ __launch_bounds__(256) void k_merge_rows_fast(const TX *__restrict__ 
     constexpr int VEC = 16 / sizeof(TX);
     const int lane = threadIdx.x & 63;
     const int To = T_ - r;
-    const int rg_per_group = (To + R - 1) / R;
-    const int64_t w = (int64_t)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int64_t n_main = (int64_t)n * rg_per_group;
-    const int64_t n_edge = (OP == OP_DROP) ? 0 : (int64_t)n * r;
-    if (w >= n_main + n_edge) {
+    // Grid: x = the blocks of ONE merge group (four waves each), (y, z) = the group -- so that no wave starts with
+    // integer divisions of a flat index (they were ~250 dependent scalar instructions before the first load).  Waves
+    // 0 .. rg-1 of a group stream R output rows each, the next r waves are the edge waves, the rest leave; the class
+    // tokens kept aside by the regrouped callers are handled by the blocks of the (y, z) rows behind the n groups.
+    // (rg_per_group = ceil((T - r) / R), from the host)
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int gy = (int)(blockIdx.z * gridDim.y + blockIdx.y);
+    const int lw = (int)blockIdx.x * (int)(blockDim.x >> 6) + wv;
+    if (gy >= n) {
         // the class tokens kept aside by the regrouped callers (timesformer.py:89,107): plain row copies
-        const int64_t b = w - n_main - n_edge;
+        const int64_t b = ((int64_t)(gy - n) * gridDim.x + blockIdx.x) * (blockDim.x >> 6) + wv;
         if (b < cls_rows) {
             const uint4 *src = reinterpret_cast<const uint4 *>(x + b * lin.outer_stride);
             uint4 *dst = reinterpret_cast<uint4 *>(xout + b * lout.outer_stride);
@@ -560,13 +711,13 @@ __global__ __launch_bounds__(256) void k_merge_rows_fast(const TX *__restrict__ 
         }
         return;
     }
-    if (w >= n_main) {
+    const int g = gy;
+    if (lw >= rg_per_group) {
         // edge waves: one per (group, rank k).  The wave of the FIRST edge into a destination builds that
         // row (all its sources, rank order); the others leave.  Destinations with sources therefore never
         // hold up the streaming waves above, and run concurrently with them.
-        const int64_t ew = w - n_main;
-        const int g = (int)(ew / r);
-        const int k = (int)(ew - (int64_t)g * r);
+        const int k = lw - rg_per_group;
+        if (OP == OP_DROP || k >= r) return;
         const int64_t *dstg = dst_idx + (int64_t)g * r;
         const int j = (int)dstg[k];
         bool earlier = false;
@@ -582,12 +733,12 @@ __global__ __launch_bounds__(256) void k_merge_rows_fast(const TX *__restrict__ 
             src_idx + (int64_t)g * r, dstg, keep, group_ptr(xout, lout, g) + (int64_t)o * lout.tok_stride,
             sout ? sout + (int64_t)g * To + o : nullptr, lane, &ln,
             LN ? group_ptr(reinterpret_cast<TX *>(ln.y), lout, g) + (int64_t)o * lout.tok_stride : nullptr,
-            (LN && ln.addend) ? group_ptr(reinterpret_cast<const TX *>(ln.addend), ln.a_own ? ln.la : lin, g) : nullptr,
+            (LN && ln.addend) ? (ln.a_own ? group_ptr(reinterpret_cast<const TX *>(ln.addend), ln.la, g)
+                                          : group_ptr(reinterpret_cast<const TX *>(ln.addend), lin, g)) : nullptr,
             lsout ? lsout + (int64_t)g * To + o : nullptr, ln.a_own ? ln.la.tok_stride : lin.tok_stride);
         return;
     }
-    const int g = (int)(w / rg_per_group);
-    const int o0 = (int)(w - (int64_t)g * rg_per_group) * R;
+    const int o0 = lw * R;
     const int T1 = (T_ + 1) >> 1, U = T1 - r;
     const TX *xg = group_ptr(x, lin, g);
     TX *og = group_ptr(xout, lout, g);
@@ -602,27 +753,25 @@ __global__ __launch_bounds__(256) void k_merge_rows_fast(const TX *__restrict__ 
     // measured in round 2: no gain for this kernel, a loss for the plain merge -- the kernel is bound by its vector
     // instructions, not by latency.)
     const int d_first = (OP != OP_DROP && lane < r) ? (int)dstg[lane] : -2;
-    int my_tok = 0, my_j = -1;
+    // (branch-free: every lane computes, lanes that own no row read a harmless entry -- no divergent control flow
+    // and no wait between the index loads and the row loads)
     float my_s = 1.0f;
-    bool my_valid = false;
-    if (lane < R) {
-        const int o = o0 + lane;
-        if (o < To) {
-            my_valid = true;
-            bool is_dst;
-            int idx;
-            decode_out_row(o, U, distill, is_dst, idx);
-            if (is_dst) {
-                my_tok = 2 * idx + 1;
-                my_j = idx;
-            } else {
-                my_tok = 2 * (int)unm_idx[(int64_t)g * U + idx];
-            }
-        }
+    const bool my_valid = lane < R && (o0 + lane) < To;
+    bool is_dst;
+    int idx;
+    decode_out_row(my_valid ? o0 + lane : 0, U, distill, is_dst, idx);
+    int my_tok = 2 * idx + 1, my_j = idx;
+    if (U > 0) {  // (wave-uniform; unm_idx may be absent when every even token is merged away)
+        const int ut = 2 * (int)unm_idx[(int64_t)g * U + ((my_valid && !is_dst) ? idx : 0)];
+        my_tok = is_dst ? my_tok : ut;
+        my_j = is_dst ? my_j : -1;
     }
-    TS my_s_raw;
-    const bool load_size = (OP == OP_WAVG) && sg && my_valid;
-    if (load_size) my_s_raw = sg[my_tok];
+    my_tok = my_valid ? my_tok : 0;
+    my_j = my_valid ? my_j : -1;
+    // (the size is read unconditionally -- from the tokens themselves when there are no sizes -- so that no branch
+    // invites the compiler to wait for it before the row loads have been issued)
+    const bool load_size = (OP == OP_WAVG) && sg;  // wave-uniform
+    const TS my_s_raw = (load_size ? sg : reinterpret_cast<const TS *>(xg))[my_tok];
     const unsigned long long vmask = __ballot(my_valid);
     const int tok0 = __builtin_amdgcn_readlane(my_tok, 0), tok1 = __builtin_amdgcn_readlane(my_tok, 1),
               tok2 = __builtin_amdgcn_readlane(my_tok, 2), tok3 = __builtin_amdgcn_readlane(my_tok, 3);
@@ -658,20 +807,21 @@ __global__ __launch_bounds__(256) void k_merge_rows_fast(const TX *__restrict__ 
         const int t = rr == 0 ? tok0 : (rr == 1 ? tok1 : (rr == 2 ? tok2 : tok3));
         const bool ok = (rr == 0 ? ok0 : (rr == 1 ? ok1 : (rr == 2 ? ok2 : ok3))) && (q < total);
         rowof[it] = ok ? rr : -1;
-        if (ok)
-            raw[it] = ld16(reinterpret_cast<const char *>(xg + (int64_t)t * lin.tok_stride) + cc * 16);
+        // unconditional: a lane without a chunk re-reads the start of the wave's first row (always a real token) and
+        // ignores it -- no control flow around the loads, so all of them are in flight together
+        raw[it] = ld16(reinterpret_cast<const char *>(xg + (int64_t)(ok ? t : tok0) * lin.tok_stride) + (ok ? cc : 0) * 16);
     }
     if (LN && ln.addend) {  // fused residual: the rows that are merged are round(x + addend)
-        const TX *agp = group_ptr(reinterpret_cast<const TX *>(ln.addend), ln.a_own ? ln.la : lin, g);
+        const TX *agp = ln.a_own ? group_ptr(reinterpret_cast<const TX *>(ln.addend), ln.la, g)
+                                 : group_ptr(reinterpret_cast<const TX *>(ln.addend), lin, g);
         const int64_t astride = ln.a_own ? ln.la.tok_stride : lin.tok_stride;
         uint4 rawa[NIT];
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int rr = rowof[it];
-            if (rr < 0) continue;
             const int q = it * WAVE + lane;
-            const int cc = q - rr * cpr;
-            const int t = rr == 0 ? tok0 : (rr == 1 ? tok1 : (rr == 2 ? tok2 : tok3));
+            const int cc = rr < 0 ? 0 : q - rr * cpr;
+            const int t = rr <= 0 ? tok0 : (rr == 1 ? tok1 : (rr == 2 ? tok2 : tok3));
             rawa[it] = ld16(reinterpret_cast<const char *>(agp + (int64_t)t * astride) + cc * 16);
         }
 #pragma unroll
@@ -684,7 +834,16 @@ __global__ __launch_bounds__(256) void k_merge_rows_fast(const TX *__restrict__ 
             __builtin_memcpy(&raw[it], &ps, 16);
         }
     }
-    if (load_size) my_s = to_f32(my_s_raw);
+    // the bias folded into x' (xbias): its chunks are requested here, ahead of the stores that need them
+    uint4 xbraw[NIT];
+    if (LN && ln.xbias) {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int rr = rowof[it];
+            xbraw[it] = *(reinterpret_cast<const uint4 *>(ln.xbias) + (rr < 0 ? 0 : it * WAVE + lane - rr * cpr));
+        }
+    }
+    my_s = (load_size && my_valid) ? to_f32(my_s_raw) : 1.0f;
     const float sz0 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(my_s), 0)),
                 sz1 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(my_s), 1)),
                 sz2 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(my_s), 2)),
@@ -713,72 +872,20 @@ __global__ __launch_bounds__(256) void k_merge_rows_fast(const TX *__restrict__ 
         const int cc = q - rr * cpr;
         char *xdst = reinterpret_cast<char *>(og + (int64_t)(o0 + rr) * lout.tok_stride) + cc * 16;
         if (LN && ln.xbias)
-            st16(xdst, add_xbias<TX, VEC>(outv, reinterpret_cast<const TX *>(ln.xbias) + cc * VEC));
+            st16(xdst, add_xbias<TX, VEC>(outv, reinterpret_cast<const TX *>(&xbraw[it])));
         else
             st16(xdst, outv);
         if (LN) raw[it] = outv;  // keep the merged bits: LayerNorm runs on x' itself (what is written without xbias)
     }
     if (LN) {
-        // statistics of the (up to) four rows of this wave, two passes over the registers (mean, then centred
-        // variance -- a row far from zero keeps its variance, as in torch's LayerNorm): per-lane partial sums by
-        // row, four independent wave reductions per pass
-        float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f, q0 = 0.0f, q1 = 0.0f, q2 = 0.0f, q3 = 0.0f;
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const int rr = rowof[it];
-            Pack<TX, VEC> pk;
-            __builtin_memcpy(&pk, &raw[it], 16);
-            float t = 0.0f;
-#pragma unroll
-            for (int e = 0; e < VEC; ++e) t += to_f32(pk.e[e]);
-            s0 += rr == 0 ? t : 0.0f;
-            s1 += rr == 1 ? t : 0.0f;
-            s2 += rr == 2 ? t : 0.0f;
-            s3 += rr == 3 ? t : 0.0f;
-        }
-        const float fc = (float)C;
-        const float m0 = wave_sum(s0) / fc, m1 = wave_sum(s1) / fc, m2 = wave_sum(s2) / fc, m3 = wave_sum(s3) / fc;
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const int rr = rowof[it];
-            const float m = rr == 0 ? m0 : (rr == 1 ? m1 : (rr == 2 ? m2 : m3));
-            Pack<TX, VEC> pk;
-            __builtin_memcpy(&pk, &raw[it], 16);
-            float u = 0.0f;
-#pragma unroll
-            for (int e = 0; e < VEC; ++e) {
-                const float d = to_f32(pk.e[e]) - m;
-                u = __fmaf_rn(d, d, u);
-            }
-            q0 += rr == 0 ? u : 0.0f;
-            q1 += rr == 1 ? u : 0.0f;
-            q2 += rr == 2 ? u : 0.0f;
-            q3 += rr == 3 ? u : 0.0f;
-        }
-        const float v0 = wave_sum(q0) / fc, v1 = wave_sum(q1) / fc, v2 = wave_sum(q2) / fc, v3 = wave_sum(q3) / fc;
-        const float r0 = 1.0f / __builtin_sqrtf(v0 + ln.eps), r1 = 1.0f / __builtin_sqrtf(v1 + ln.eps),
-                    r2 = 1.0f / __builtin_sqrtf(v2 + ln.eps), r3 = 1.0f / __builtin_sqrtf(v3 + ln.eps);
-        const TX *lw = reinterpret_cast<const TX *>(ln.weight), *lb = reinterpret_cast<const TX *>(ln.bias);
+        // LayerNorm of the (up to) four rows of this wave as they were stored (ln_rows above)
         TX *yg = group_ptr(reinterpret_cast<TX *>(ln.y), lout, g);
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const int rr = rowof[it];
-            if (rr < 0) continue;
-            const int q = it * WAVE + lane;
-            const int cc = q - rr * cpr;
-            const float m = rr == 0 ? m0 : (rr == 1 ? m1 : (rr == 2 ? m2 : m3));
-            const float rs = rr == 0 ? r0 : (rr == 1 ? r1 : (rr == 2 ? r2 : r3));
-            Pack<TX, VEC> pk;
-            __builtin_memcpy(&pk, &raw[it], 16);
-            float w8[VEC], b8[VEC];
-            load_pack<TX, VEC>(lw + cc * VEC, w8);
-            load_pack<TX, VEC>(lb + cc * VEC, b8);
-#pragma unroll
-            for (int e = 0; e < VEC; ++e) pk.e[e] = from_f32<TX>((to_f32(pk.e[e]) - m) * rs * w8[e] + b8[e]);
-            uint4 yv;
-            __builtin_memcpy(&yv, &pk, 16);
-            st16(reinterpret_cast<char *>(yg + (int64_t)(o0 + rr) * lout.tok_stride) + cc * 16, yv);
-        }
+        const int64_t ystride = lout.tok_stride;
+        ln_rows<TX, NIT>(raw, rowof, R, cpr, C, ln.eps, reinterpret_cast<const TX *>(ln.weight),
+                         reinterpret_cast<const TX *>(ln.bias), lane,
+                         [&](int, int rr, int cc, const uint4 &yv) __attribute__((always_inline)) {
+                             st16(reinterpret_cast<char *>(yg + (int64_t)(o0 + rr) * ystride) + cc * 16, yv);
+                         });
     }
     if (OP == OP_WAVG && lane < R && my_valid) {
         const bool mine_has_edges = lane == 0 ? e0 : (lane == 1 ? e1 : (lane == 2 ? e2 : e3));
@@ -818,86 +925,36 @@ __global__ __launch_bounds__(256) void k_add_ln_rows(const TX *__restrict__ x, c
         }
     }
     uint4 *xo = reinterpret_cast<uint4 *>(xout + row0 * C);
-    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f, q0 = 0.0f, q1 = 0.0f, q2 = 0.0f, q3 = 0.0f;
     int rowof[NIT];
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
         const int q = it * WAVE + lane;
         const int rr = (q >= cpr) + (q >= 2 * cpr) + (q >= 3 * cpr);
         rowof[it] = q < total ? rr : -1;
-        if (q >= total) continue;
-        Pack<TX, VEC> ps;
+        if (q >= total || !add) continue;
+        Pack<TX, VEC> ps, pa;
         __builtin_memcpy(&ps, &raw[it], 16);
-        if (add) {
-            Pack<TX, VEC> pa;
-            __builtin_memcpy(&pa, &rawa[it], 16);
-            ps = add_packs<TX, VEC>(ps, pa);
-            __builtin_memcpy(&raw[it], &ps, 16);
-            st16(xo + q, raw[it]);
-        }
-        float t = 0.0f;
-#pragma unroll
-        for (int e = 0; e < VEC; ++e) t += to_f32(ps.e[e]);
-        s0 += rr == 0 ? t : 0.0f;
-        s1 += rr == 1 ? t : 0.0f;
-        s2 += rr == 2 ? t : 0.0f;
-        s3 += rr == 3 ? t : 0.0f;
+        __builtin_memcpy(&pa, &rawa[it], 16);
+        ps = add_packs<TX, VEC>(ps, pa);
+        __builtin_memcpy(&raw[it], &ps, 16);
+        st16(xo + q, raw[it]);
     }
-    const float fc = (float)C;
-    const float m0 = wave_sum(s0) / fc, m1 = wave_sum(s1) / fc, m2 = wave_sum(s2) / fc, m3 = wave_sum(s3) / fc;
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) {  // second pass over the registers: centred variance
-        const int rr = rowof[it];
-        if (rr < 0) continue;
-        const float m = rr == 0 ? m0 : (rr == 1 ? m1 : (rr == 2 ? m2 : m3));
-        Pack<TX, VEC> pk;
-        __builtin_memcpy(&pk, &raw[it], 16);
-        float u = 0.0f;
-#pragma unroll
-        for (int e = 0; e < VEC; ++e) {
-            const float d = to_f32(pk.e[e]) - m;
-            u = __fmaf_rn(d, d, u);
-        }
-        q0 += rr == 0 ? u : 0.0f;
-        q1 += rr == 1 ? u : 0.0f;
-        q2 += rr == 2 ? u : 0.0f;
-        q3 += rr == 3 ? u : 0.0f;
-    }
-    const float r0 = 1.0f / __builtin_sqrtf(wave_sum(q0) / fc + ln.eps),
-                r1 = 1.0f / __builtin_sqrtf(wave_sum(q1) / fc + ln.eps),
-                r2 = 1.0f / __builtin_sqrtf(wave_sum(q2) / fc + ln.eps),
-                r3 = 1.0f / __builtin_sqrtf(wave_sum(q3) / fc + ln.eps);
-    const TX *lw = reinterpret_cast<const TX *>(ln.weight), *lb = reinterpret_cast<const TX *>(ln.bias);
-    uint4 *yo = reinterpret_cast<uint4 *>(reinterpret_cast<TX *>(ln.y) + row0 * C);
     // y_group > 0: rows come in groups of y_group whose FIRST row (a class token) has no place in y -- y holds the other
     // y_group - 1 rows of every group, compacted (TimeSformer's temporal_norm1 feeds only the patch tokens,
     // tome/patch/timesformer.py:24-26, so `xn[:, 1:]` regrouped '(b p) t m' is a view instead of a copy)
     const int yg = ln.y_group;
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-        const int rr = rowof[it];
-        if (rr < 0) continue;
-        const int q = it * WAVE + lane;
-        const int cc = q - rr * cpr;
-        const float m = rr == 0 ? m0 : (rr == 1 ? m1 : (rr == 2 ? m2 : m3));
-        const float rs = rr == 0 ? r0 : (rr == 1 ? r1 : (rr == 2 ? r2 : r3));
-        Pack<TX, VEC> pk;
-        __builtin_memcpy(&pk, &raw[it], 16);
-        float w8[VEC], b8[VEC];
-        load_pack<TX, VEC>(lw + cc * VEC, w8);
-        load_pack<TX, VEC>(lb + cc * VEC, b8);
-#pragma unroll
-        for (int e = 0; e < VEC; ++e) pk.e[e] = from_f32<TX>((to_f32(pk.e[e]) - m) * rs * w8[e] + b8[e]);
-        uint4 yv;
-        __builtin_memcpy(&yv, &pk, 16);
-        if (yg > 0) {
-            const int64_t grow = row0 + rr, gb = grow / yg;
-            if (grow - gb * yg == 0) continue;
-            st16(reinterpret_cast<uint4 *>(reinterpret_cast<TX *>(ln.y) + (grow - gb - 1) * C) + cc, yv);
-        } else {
-            st16(yo + q, yv);
-        }
-    }
+    TX *yb = reinterpret_cast<TX *>(ln.y);
+    ln_rows<TX, NIT>(raw, rowof, nrow, cpr, C, ln.eps, reinterpret_cast<const TX *>(ln.weight),
+                     reinterpret_cast<const TX *>(ln.bias), lane,
+                     [&](int, int rr, int cc, const uint4 &yv) __attribute__((always_inline)) {
+                         int64_t yrow = row0 + rr;
+                         if (yg > 0) {
+                             const int64_t gb = yrow / yg;
+                             if (yrow - gb * yg == 0) return;
+                             yrow -= gb + 1;
+                         }
+                         st16(reinterpret_cast<uint4 *>(yb + yrow * C) + cc, yv);
+                     });
 }
 
 // k_unmerge_rows: merge.py:87-100 as a scatter from the merged sequence: one wave per INPUT row; a
@@ -1044,80 +1101,32 @@ __global__ __launch_bounds__(256) void k_add_ln_regroup(const TX *__restrict__ x
         if (ar >= 0) rawa[it] = ld16(reinterpret_cast<const uint4 *>(a + ar * C) + (q - rr * cpr));
     }
     uint4 *xo = reinterpret_cast<uint4 *>(xout + row0 * C);
-    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f, q0 = 0.0f, q1 = 0.0f, q2 = 0.0f, q3 = 0.0f;
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
         const int rr = rowof[it];
         if (rr < 0) continue;
         const int q = it * WAVE + lane;
         const int64_t ar = rr == 0 ? arow[0] : (rr == 1 ? arow[1] : (rr == 2 ? arow[2] : arow[3]));
-        Pack<TX, VEC> ps;
-        __builtin_memcpy(&ps, &raw[it], 16);
         if (ar >= 0) {
-            Pack<TX, VEC> pa;
+            Pack<TX, VEC> ps, pa;
+            __builtin_memcpy(&ps, &raw[it], 16);
             __builtin_memcpy(&pa, &rawa[it], 16);
             ps = add_packs<TX, VEC>(ps, pa);
             __builtin_memcpy(&raw[it], &ps, 16);
         }
         st16(xo + q, raw[it]);
-        float t = 0.0f;
-#pragma unroll
-        for (int e = 0; e < VEC; ++e) t += to_f32(ps.e[e]);
-        s0 += rr == 0 ? t : 0.0f;
-        s1 += rr == 1 ? t : 0.0f;
-        s2 += rr == 2 ? t : 0.0f;
-        s3 += rr == 3 ? t : 0.0f;
     }
-    const float fc = (float)C;
-    const float m0 = wave_sum(s0) / fc, m1 = wave_sum(s1) / fc, m2 = wave_sum(s2) / fc, m3 = wave_sum(s3) / fc;
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-        const int rr = rowof[it];
-        if (rr < 0) continue;
-        const float m = rr == 0 ? m0 : (rr == 1 ? m1 : (rr == 2 ? m2 : m3));
-        Pack<TX, VEC> pk;
-        __builtin_memcpy(&pk, &raw[it], 16);
-        float u = 0.0f;
-#pragma unroll
-        for (int e = 0; e < VEC; ++e) {
-            const float d = to_f32(pk.e[e]) - m;
-            u = __fmaf_rn(d, d, u);
-        }
-        q0 += rr == 0 ? u : 0.0f;
-        q1 += rr == 1 ? u : 0.0f;
-        q2 += rr == 2 ? u : 0.0f;
-        q3 += rr == 3 ? u : 0.0f;
-    }
-    const float r0 = 1.0f / __builtin_sqrtf(wave_sum(q0) / fc + ln.eps),
-                r1 = 1.0f / __builtin_sqrtf(wave_sum(q1) / fc + ln.eps),
-                r2 = 1.0f / __builtin_sqrtf(wave_sum(q2) / fc + ln.eps),
-                r3 = 1.0f / __builtin_sqrtf(wave_sum(q3) / fc + ln.eps);
-    const TX *lw = reinterpret_cast<const TX *>(ln.weight), *lb = reinterpret_cast<const TX *>(ln.bias);
     TX *yb = reinterpret_cast<TX *>(ln.y);
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-        const int rr = rowof[it];
-        if (rr < 0) continue;
-        const int q = it * WAVE + lane;
-        const int cc = q - rr * cpr;
-        const float m = rr == 0 ? m0 : (rr == 1 ? m1 : (rr == 2 ? m2 : m3));
-        const float rs = rr == 0 ? r0 : (rr == 1 ? r1 : (rr == 2 ? r2 : r3));
-        const int64_t ar = rr == 0 ? arow[0] : (rr == 1 ? arow[1] : (rr == 2 ? arow[2] : arow[3]));
-        const int64_t yr = rr == 0 ? yrow[0] : (rr == 1 ? yrow[1] : (rr == 2 ? yrow[2] : yrow[3]));
-        Pack<TX, VEC> pk;
-        __builtin_memcpy(&pk, &raw[it], 16);
-        float w8[VEC], b8[VEC];
-        load_pack<TX, VEC>(lw + cc * VEC, w8);
-        load_pack<TX, VEC>(lb + cc * VEC, b8);
-#pragma unroll
-        for (int e = 0; e < VEC; ++e) pk.e[e] = from_f32<TX>((to_f32(pk.e[e]) - m) * rs * w8[e] + b8[e]);
-        uint4 yv;
-        __builtin_memcpy(&yv, &pk, 16);
-        uint4 *yp = reinterpret_cast<uint4 *>(yb + yr * C) + cc;
-        st16(yp, yv);
-        if (ar < 0)  // class token: the same normalised row in front of every frame's tokens
-            for (int t = 1; t < F; ++t) st16(yp + (int64_t)t * (1 + P) * cpr, yv);
-    }
+    ln_rows<TX, NIT>(raw, rowof, nrow, cpr, C, ln.eps, reinterpret_cast<const TX *>(ln.weight),
+                     reinterpret_cast<const TX *>(ln.bias), lane,
+                     [&](int, int rr, int cc, const uint4 &yv) __attribute__((always_inline)) {
+                         const int64_t ar = rr == 0 ? arow[0] : (rr == 1 ? arow[1] : (rr == 2 ? arow[2] : arow[3]));
+                         const int64_t yr = rr == 0 ? yrow[0] : (rr == 1 ? yrow[1] : (rr == 2 ? yrow[2] : yrow[3]));
+                         uint4 *yp = reinterpret_cast<uint4 *>(yb + yr * C) + cc;
+                         st16(yp, yv);
+                         if (ar < 0)  // class token: the same normalised row in front of every frame's tokens
+                             for (int t = 1; t < F; ++t) st16(yp + (int64_t)t * (1 + P) * cpr, yv);
+                     });
 }
 
 // k_gelu_erf: the activation between the two GEMMs of the MLP the patched block calls (`self.mlp(self.norm2(x))`,
