@@ -761,7 +761,10 @@ __global__ __launch_bounds__(256) void k_merge_rows_fast(const TX *__restrict__ 
     int idx;
     decode_out_row(my_valid ? o0 + lane : 0, U, distill, is_dst, idx);
     int my_tok = 2 * idx + 1, my_j = idx;
-    if (U > 0) {  // (wave-uniform; unm_idx may be absent when every even token is merged away)
+    // a wave whose rows are all destination (odd) tokens knows its tokens without reading an index: its row loads
+    // depend on no earlier load at all
+    const bool all_dst = (!distill && o0 >= U) || o0 > U;
+    if (U > 0 && !all_dst) {  // (wave-uniform; unm_idx may be absent when every even token is merged away)
         const int ut = 2 * (int)unm_idx[(int64_t)g * U + ((my_valid && !is_dst) ? idx : 0)];
         my_tok = is_dst ? my_tok : ut;
         my_j = is_dst ? my_j : -1;
@@ -777,6 +780,41 @@ __global__ __launch_bounds__(256) void k_merge_rows_fast(const TX *__restrict__ 
               tok2 = __builtin_amdgcn_readlane(my_tok, 2), tok3 = __builtin_amdgcn_readlane(my_tok, 3);
     const int j0 = __builtin_amdgcn_readlane(my_j, 0), j1 = __builtin_amdgcn_readlane(my_j, 1),
               j2 = __builtin_amdgcn_readlane(my_j, 2), j3 = __builtin_amdgcn_readlane(my_j, 3);
+    // rows that exist; which of them receive sources (and are left to the edge waves) is decided AFTER the row loads
+    // have been issued -- a row that turns out to be one is read for nothing (r of T rows), but no row load waits for
+    // dst_idx
+    const bool va0 = vmask & 1ull, va1 = vmask & 2ull, va2 = vmask & 4ull, va3 = vmask & 8ull;
+
+    // flattened chunk loop: chunk q of the R-row slab -> (row q / cpr, 16-byte column q % cpr)
+    const int total = R * cpr;
+    uint4 raw[NIT];
+    int rowof[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int q = it * WAVE + lane;
+        const int rr = (q >= cpr) + (q >= 2 * cpr) + (q >= 3 * cpr);
+        const int cc = q - rr * cpr;
+        const int t = rr == 0 ? tok0 : (rr == 1 ? tok1 : (rr == 2 ? tok2 : tok3));
+        const bool ok = (rr == 0 ? va0 : (rr == 1 ? va1 : (rr == 2 ? va2 : va3))) && (q < total);
+        rowof[it] = ok ? rr : -1;
+        // unconditional: a lane without a chunk re-reads the start of the wave's first row (always a real token) and
+        // ignores it -- no control flow around the loads, so all of them are in flight together
+        raw[it] = ld16(reinterpret_cast<const char *>(xg + (int64_t)(ok ? t : tok0) * lin.tok_stride) + (ok ? cc : 0) * 16);
+    }
+    uint4 rawa[NIT];
+    if (LN && ln.addend) {  // fused residual: the rows that are merged are round(x + addend)
+        const TX *agp = ln.a_own ? group_ptr(reinterpret_cast<const TX *>(ln.addend), ln.la, g)
+                                 : group_ptr(reinterpret_cast<const TX *>(ln.addend), lin, g);
+        const int64_t astride = ln.a_own ? ln.la.tok_stride : lin.tok_stride;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int rr = rowof[it];
+            const int q = it * WAVE + lane;
+            const int cc = rr < 0 ? 0 : q - rr * cpr;
+            const int t = rr <= 0 ? tok0 : (rr == 1 ? tok1 : (rr == 2 ? tok2 : tok3));
+            rawa[it] = ld16(reinterpret_cast<const char *>(agp + (int64_t)t * astride) + cc * 16);
+        }
+    }
     bool e0 = false, e1 = false, e2 = false, e3 = false;  // rows that receive sources
     if (OP != OP_DROP) {
         e0 = __ballot(d_first == j0) != 0ull;
@@ -792,38 +830,14 @@ __global__ __launch_bounds__(256) void k_merge_rows_fast(const TX *__restrict__ 
             e3 = e3 || (__ballot(d == j3) != 0ull);
         }
     }
-    const bool ok0 = (vmask & 1ull) && !e0, ok1 = (vmask & 2ull) && !e1, ok2 = (vmask & 4ull) && !e2,
-               ok3 = (vmask & 8ull) && !e3;
-
-    // flattened chunk loop: chunk q of the R-row slab -> (row q / cpr, 16-byte column q % cpr)
-    const int total = R * cpr;
-    uint4 raw[NIT];
-    int rowof[NIT];
+    const bool ok0 = va0 && !e0, ok1 = va1 && !e1, ok2 = va2 && !e2, ok3 = va3 && !e3;
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
-        const int q = it * WAVE + lane;
-        const int rr = (q >= cpr) + (q >= 2 * cpr) + (q >= 3 * cpr);
-        const int cc = q - rr * cpr;
-        const int t = rr == 0 ? tok0 : (rr == 1 ? tok1 : (rr == 2 ? tok2 : tok3));
-        const bool ok = (rr == 0 ? ok0 : (rr == 1 ? ok1 : (rr == 2 ? ok2 : ok3))) && (q < total);
+        const int rr = rowof[it];
+        const bool ok = rr >= 0 && (rr == 0 ? ok0 : (rr == 1 ? ok1 : (rr == 2 ? ok2 : ok3)));
         rowof[it] = ok ? rr : -1;
-        // unconditional: a lane without a chunk re-reads the start of the wave's first row (always a real token) and
-        // ignores it -- no control flow around the loads, so all of them are in flight together
-        raw[it] = ld16(reinterpret_cast<const char *>(xg + (int64_t)(ok ? t : tok0) * lin.tok_stride) + (ok ? cc : 0) * 16);
     }
-    if (LN && ln.addend) {  // fused residual: the rows that are merged are round(x + addend)
-        const TX *agp = ln.a_own ? group_ptr(reinterpret_cast<const TX *>(ln.addend), ln.la, g)
-                                 : group_ptr(reinterpret_cast<const TX *>(ln.addend), lin, g);
-        const int64_t astride = ln.a_own ? ln.la.tok_stride : lin.tok_stride;
-        uint4 rawa[NIT];
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const int rr = rowof[it];
-            const int q = it * WAVE + lane;
-            const int cc = rr < 0 ? 0 : q - rr * cpr;
-            const int t = rr <= 0 ? tok0 : (rr == 1 ? tok1 : (rr == 2 ? tok2 : tok3));
-            rawa[it] = ld16(reinterpret_cast<const char *>(agp + (int64_t)t * astride) + cc * 16);
-        }
+    if (LN && ln.addend) {
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             if (rowof[it] < 0) continue;
