@@ -1140,3 +1140,31 @@ def test_kernels_are_deterministic():
     for _ in range(3):
         for t0, t1 in zip(first, run()):
             assert torch.equal(t0, t1)
+
+
+def test_merge_wavg_ln_many_groups():
+    """More merge groups than one grid dimension holds (n > 65535: the (group) index of k_merge_rows_fast spills into
+    grid.z): x' == tome_merge_wavg bit for bit, y within one epsilon, and the regrouped form with as many class rows."""
+    from tome import _abi
+    tm = _tome()
+    n, T, C, r = 70001, 6, 16, 2
+    metric = dev(synth.normal_like((n, T, 8), 901))
+    x = dev(synth.normal_like((n, T, C), 902), torch.bfloat16)
+    a = dev(0.5 * synth.normal_like((n, T, C), 903), torch.bfloat16)
+    w = dev(1.0 + 0.1 * synth.normal_like((C,), 904), torch.bfloat16)
+    b = dev(0.1 * synth.normal_like((C,), 905), torch.bfloat16)
+    merge, _ = tm.bipartite_soft_matching(metric, r)
+    want_x, want_s = tm.merge_wavg(merge, x + a)
+    got_x, got_y, got_s = _abi.merge_wavg_ln(merge.plan, x, None, w, b, 1e-6, addend=a)
+    assert torch.equal(got_x, want_x) and torch.equal(got_s, want_s)
+    ref = torch.nn.functional.layer_norm(want_x.float(), (C,), w.float(), b.float(), 1e-6)
+    assert float(((got_y.float() - ref).abs() / ref.abs().clamp(min=1.0)).max()) <= 2 ** -7
+    # interleaved layout: B clips x F frames = n groups, one class row per clip
+    B, F = n // 7, 7
+    xf = dev(synth.normal_like((B, 1 + T * F, C), 906), torch.bfloat16)
+    plan = tm.bipartite_soft_matching(metric[:B * F], r)[0].plan
+    wx, ws = _abi.merge_wavg_regrouped(plan, xf, None, F, has_cls=True)
+    gx, gy, gs = _abi.merge_wavg_regrouped(plan, xf, None, F, has_cls=True, ln=(w, b, 1e-6))
+    assert torch.equal(gx, wx) and torch.equal(gs, ws)
+    ref = torch.nn.functional.layer_norm(wx.float(), (C,), w.float(), b.float(), 1e-6)
+    assert float(((gy.float() - ref).abs() / ref.abs().clamp(min=1.0)).max()) <= 2 ** -7

@@ -891,7 +891,7 @@ __global__ __launch_bounds__(256) void k_merge_rows_fast(const TX *__restrict__ 
             st16(xdst, outv);
         if (LN) raw[it] = outv;  // keep the merged bits: LayerNorm runs on x' itself (what is written without xbias)
     }
-    if (LN) {
+    if constexpr (LN) {
         // LayerNorm of the (up to) four rows of this wave as they were stored (ln_rows above)
         TX *yg = group_ptr(reinterpret_cast<TX *>(ln.y), lout, g);
         const int64_t ystride = lout.tok_stride;
