@@ -614,6 +614,12 @@ __global__ __launch_bounds__(256) void k_merge_rows(const TX *__restrict__ x, co
 // R rows) and issues all of its loads before touching any of them, so ~6 KiB per wave are in flight.
 // Rows that nothing merges into are moved as raw bits when their size is 1 ((x*1)/1 == x bit for bit)
 // or scaled in fp32 otherwise; the few rows that receive sources are finished by merge_dst_row.
+// How the loads stay together (checked in the ISA, tools/kernel_usage.py --keep): they are UNCONDITIONAL -- a lane
+// without a chunk re-reads the start of the wave's first row -- because hipcc sinks the first use of a conditionally
+// loaded value into the `if`, with an s_waitcnt vmcnt(0) behind every load; the size is read unconditionally for the
+// same reason; which rows receive sources is decided after the row loads are out.  Launch geometry: grid.x = the
+// blocks of one group (streaming waves, then r edge waves), grid.(y, z) = the group, class-token rows behind the
+// groups -- no wave starts with an integer division.
 // ------------------------------------------------------------------------------------------------
 #define FAST_NIT 6
 #define FAST_MAXR 4
