@@ -134,13 +134,23 @@ __global__ __launch_bounds__(256) void k_unit_rows_heads(const T *__restrict__ k
     const int64_t ntok = (int64_t)n * T_;
     const bool live = tok < ntok;
     const int64_t tk = live ? tok : ntok - 1;
-    const int g = (int)(tk / T_);
-    const int t = (int)(tk - (int64_t)g * T_);
-    const T *row = keys + (int64_t)(g / inner) * stride_n + (int64_t)(g % inner) * stride_inner + (int64_t)t * stride_t + 8 * b8;
+    // (32-bit division whenever the token count allows it -- the 64-bit one is ~100 vector instructions per lane --
+    // and none at all for the group decomposition of the plain layout)
+    int g, t;
+    if (ntok <= 0x7fffffffLL) {
+        g = (int)((uint32_t)tk / (uint32_t)T_);
+        t = (int)((uint32_t)tk - (uint32_t)g * (uint32_t)T_);
+    } else {
+        g = (int)(tk / T_);
+        t = (int)(tk - (int64_t)g * T_);
+    }
+    const T *row = keys + (int64_t)t * stride_t + 8 * b8;
+    if (inner == 1) row += (int64_t)g * stride_n;
+    else row += (int64_t)(g / inner) * stride_n + (int64_t)(g % inner) * stride_inner;
     float acc[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) acc[e] = 0.0f;
-#pragma unroll 4
+#pragma unroll 12
     for (int h = 0; h < H; ++h) {
         float kv[8];
         Load8<T>::run(row + (int64_t)h * stride_h, kv);
