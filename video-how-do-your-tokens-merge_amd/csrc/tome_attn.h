@@ -533,17 +533,29 @@ __global__ __launch_bounds__(256) void k_trajectory_mix(const TX *__restrict__ q
     for (int i = 0; i < 2; ++i) {
         const int c = lane + 64 * i;
         const bool on = c < chunks;
-        float qv[8];
-        if (on) load_pack<TX, 8>(qr + 8 * c, qv);
-        uint4 kraw[TRAJ_MAXF];
+        // Every load is unconditional (a lane without a chunk reads chunk 0, a frame past F reads frame F-1, both
+        // ignored): with the loads inside `if (on && f < F)` hipcc put an s_waitcnt vmcnt(0) in front of every load of
+        // the second group, one round trip per frame.  k2 AND val are requested before any arithmetic.
+        const int cl = on ? c : 0;
+        uint4 kraw[TRAJ_MAXF], vraw[TRAJ_MAXF];
 #pragma unroll
-        for (int f = 0; f < TRAJ_MAXF; ++f)
-            if (on && f < F) kraw[f] = traj_ld16(kr + (int64_t)f * k_row + 8 * c);
+        for (int f = 0; f < TRAJ_MAXF; ++f) kraw[f] = traj_ld16(kr + (int64_t)(f < F ? f : F - 1) * k_row + 8 * cl);
+        const uint4 qraw = *reinterpret_cast<const uint4 *>(qr + 8 * cl);
+#pragma unroll
+        for (int f = 0; f < TRAJ_MAXF; ++f) vraw[f] = traj_ld16(vr + (int64_t)(f < F ? f : F - 1) * v_row + 8 * cl);
+        __builtin_amdgcn_sched_barrier(0);  // (the scheduler would otherwise sink the val loads below the dot products)
+        float qv[8];
+        {
+            Pack<TX, 8> pq;
+            __builtin_memcpy(&pq, &qraw, 16);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) qv[e] = to_f32(pq.e[e]);
+        }
         float lg[TRAJ_MAXF];
 #pragma unroll
         for (int f = 0; f < TRAJ_MAXF; ++f) {
             float d = 0.0f;
-            if (on && f < F) {
+            {
                 Pack<TX, 8> pk;
                 __builtin_memcpy(&pk, &kraw[f], 16);
 #pragma unroll
@@ -573,15 +585,11 @@ __global__ __launch_bounds__(256) void k_trajectory_mix(const TX *__restrict__ q
             float *tp = tattn + ((b * H + h) * S + s) * F;
             for (int f = 0; f < F; ++f) tp[f] = w[i][f];
         }
-        uint4 vraw[TRAJ_MAXF];
-#pragma unroll
-        for (int f = 0; f < TRAJ_MAXF; ++f)
-            if (on && f < F) vraw[f] = traj_ld16(vr + (int64_t)f * v_row + 8 * c);
 #pragma unroll
         for (int e = 0; e < 8; ++e) acc[i][e] = 0.0f;
 #pragma unroll
         for (int f = 0; f < TRAJ_MAXF; ++f) {
-            if (on && f < F) {
+            if (f < F) {  // (wave-uniform)
                 Pack<TX, 8> pk;
                 __builtin_memcpy(&pk, &vraw[f], 16);
 #pragma unroll
