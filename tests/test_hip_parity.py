@@ -1168,3 +1168,81 @@ def test_merge_wavg_ln_many_groups():
     assert torch.equal(gx, wx) and torch.equal(gs, ws)
     ref = torch.nn.functional.layer_norm(wx.float(), (C,), w.float(), b.float(), 1e-6)
     assert float(((gy.float() - ref).abs() / ref.abs().clamp(min=1.0)).max()) <= 2 ** -7
+
+
+def test_merge_wavg_ln_fused_random_shapes():
+    """Seeded sweep over the fused kernel's shape space (1-4 rows per wave, 3 and 6 chunks per lane, groups of 2 tokens,
+    every even token merged away, class token on / off, sizes on / off, residual on / off, folded bias on / off, both
+    16-bit formats): x' and the sizes equal the unfused composition bit for bit, y is the LayerNorm of x' within one
+    epsilon of the format."""
+    from tome import _abi
+    tm = _tome()
+    rng = np.random.default_rng(20261004)
+    widths = [8, 16, 64, 96, 128, 256, 384, 512, 768, 1024]
+    for case in range(48):
+        n = int(rng.integers(1, 5))
+        T = int(rng.choice([2, 3, 5, 8, 17, 50, 197, 300]))
+        C = int(rng.choice(widths))
+        cls = bool(rng.integers(0, 2)) and T >= 3
+        rmax = (T - (1 if cls else 0)) // 2
+        if rmax < 1:
+            continue
+        r = int(rng.choice([1, rmax, int(rng.integers(1, rmax + 1))]))
+        dtype = torch.bfloat16 if rng.integers(0, 2) else torch.float16
+        tol = 2 ** -7 if dtype == torch.bfloat16 else 2 ** -10
+        seed = 7000 + 11 * case
+        metric = dev(synth.normal_like((n, T, 16), seed))
+        x = dev(synth.normal_like((n, T, C), seed + 1), dtype)
+        a = dev(0.5 * synth.normal_like((n, T, C), seed + 2), dtype) if rng.integers(0, 2) else None
+        size = dev(synth.small_ints((n, T, 1), seed + 3, 1, 5), dtype) if rng.integers(0, 2) else None
+        ob = dev(0.3 * synth.normal_like((C,), seed + 4), dtype) if rng.integers(0, 2) else None
+        w = dev(1.0 + 0.1 * synth.normal_like((C,), seed + 5), dtype)
+        b = dev(0.1 * synth.normal_like((C,), seed + 6), dtype)
+        merge, _ = tm.bipartite_soft_matching(metric, r, cls)
+        want_x, want_s = tm.merge_wavg(merge, x if a is None else x + a, size)
+        got_x, got_y, got_s = _abi.merge_wavg_ln(merge.plan, x, size, w, b, 1e-6, addend=a, out_bias=ob)
+        tag = f"case {case}: n={n} T={T} C={C} r={r} cls={cls} {dtype} addend={a is not None} size={size is not None} bias={ob is not None}"
+        assert torch.equal(got_x, want_x if ob is None else want_x + ob), tag
+        assert torch.equal(got_s, want_s), tag
+        ref = torch.nn.functional.layer_norm(want_x.float(), (C,), w.float(), b.float(), 1e-6)
+        assert float(((got_y.float() - ref).abs() / ref.abs().clamp(min=1.0)).max()) <= tol, tag
+
+
+def test_regrouped_and_layernorm_random_shapes():
+    """Seeded sweep over the interleaved layout (B clips x F frames, class row per clip) and the LayerNorm entry points:
+    fused regrouped merge == add, tome_merge_wavg_regrouped, LayerNorm (bit-exact x' and sizes, y within one epsilon);
+    tome_add_layernorm with / without addend and with the class row left out agree with each other bit for bit."""
+    from tome import _abi
+    tm = _tome()
+    rng = np.random.default_rng(4102026)
+    for case in range(32):
+        B, F = int(rng.integers(1, 4)), int(rng.choice([1, 2, 4, 8]))
+        P = int(rng.choice([2, 3, 9, 36, 100, 196]))
+        C = int(rng.choice([8, 64, 128, 384, 768, 1024]))
+        r = int(rng.integers(1, P // 2 + 1))
+        dtype = torch.bfloat16 if rng.integers(0, 2) else torch.float16
+        tol = 2 ** -7 if dtype == torch.bfloat16 else 2 ** -10
+        seed = 9100 + 13 * case
+        xf = dev(synth.normal_like((B, 1 + P * F, C), seed), dtype)
+        res = dev(0.5 * synth.normal_like((B, 1 + P * F, C), seed + 1), dtype)
+        size = dev(synth.small_ints((B * F, P, 1), seed + 2, 1, 4), dtype) if rng.integers(0, 2) else None
+        ob = dev(0.3 * synth.normal_like((C,), seed + 3), dtype) if rng.integers(0, 2) else None
+        w = dev(1.0 + 0.1 * synth.normal_like((C,), seed + 4), dtype)
+        b = dev(0.1 * synth.normal_like((C,), seed + 5), dtype)
+        plan = tm.bipartite_soft_matching(dev(synth.normal_like((B * F, P, 16), seed + 6)), r)[0].plan
+        tag = f"case {case}: B={B} F={F} P={P} C={C} r={r} {dtype} size={size is not None} bias={ob is not None}"
+        wx, ws = _abi.merge_wavg_regrouped(plan, xf + res, size, F, has_cls=True)
+        gx, gy, gs = _abi.merge_wavg_regrouped(plan, xf, size, F, has_cls=True, ln=(w, b, 1e-6), addend=res, out_bias=ob)
+        assert torch.equal(gx, wx if ob is None else wx + ob) and torch.equal(gs, ws), tag
+        ref = torch.nn.functional.layer_norm(wx.float(), (C,), w.float(), b.float(), 1e-6)
+        assert float(((gy.float() - ref).abs() / ref.abs().clamp(min=1.0)).max()) <= tol, tag
+        # LayerNorm entry points on the merged tokens
+        xo, yo = _abi.add_layernorm(wx, gy, w, b, 1e-6)
+        assert torch.equal(xo, wx + gy), tag
+        assert torch.equal(_abi.add_layernorm(xo, None, w, b, 1e-6)[1], yo), tag
+        if wx.shape[1] >= 2:
+            xs, ys = _abi.add_layernorm(wx, gy, w, b, 1e-6, skip_first=True)
+            assert torch.equal(xs, xo) and torch.equal(ys, yo[:, 1:]), tag
+            assert torch.equal(_abi.add_layernorm(xo, None, w, b, 1e-6, skip_first=True)[1], ys), tag
+        refy = torch.nn.functional.layer_norm(xo.float(), (C,), w.float(), b.float(), 1e-6)
+        assert float(((yo.float() - refy).abs() / refy.abs().clamp(min=1.0)).max()) <= tol, tag
