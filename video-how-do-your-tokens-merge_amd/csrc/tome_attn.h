@@ -269,7 +269,9 @@ __global__ __launch_bounds__(64 * WAVES, 2) void k_prop_attention(AttnArgs a) { 
             c1[4 * g + 2] = __builtin_fmaf(bfac, b1.z, c1[4 * g + 2]); c1[4 * g + 3] = __builtin_fmaf(bfac, b1.w, c1[4 * g + 3]);
         }
     };
-    auto scores = [&](int S, const att_f32x16 &cinit) __attribute__((always_inline)) {
+    // (first_half_only: keys 32..63 of the tile lie past the end -- their weights are forced to zero anyway, so their
+    // four matrix instructions are left out; wave-uniform)
+    auto scores = [&](int S, const att_f32x16 &cinit, bool first_half_only = false) __attribute__((always_inline)) {
         // block 0 (keys 0..31) completes before block 1 starts: its weights can be taken while block 1 multiplies
         s0 = cinit;
         s1 = cinit;
@@ -277,10 +279,12 @@ __global__ __launch_bounds__(64 * WAVES, 2) void k_prop_attention(AttnArgs a) { 
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks)
             s0 = AttMfma<TX>::run(*reinterpret_cast<const att_s16x8 *>(kbase + S * ATT_BN * ATT_KS + 16 * ks), qf[ks], s0);
+        if (!first_half_only) {
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
-            s1 = AttMfma<TX>::run(*reinterpret_cast<const att_s16x8 *>(kbase + S * ATT_BN * ATT_KS + 32 * ATT_KS + 16 * ks),
-                                  qf[ks], s1);
+            for (int ks = 0; ks < 4; ++ks)
+                s1 = AttMfma<TX>::run(*reinterpret_cast<const att_s16x8 *>(kbase + S * ATT_BN * ATT_KS + 32 * ATT_KS + 16 * ks),
+                                      qf[ks], s1);
+        }
     };
     // P (fp32 weights in s0, s1) -> the four 16-bit B fragments of O^T += V^T P^T
     att_s16x8 pf[2][2];
@@ -332,9 +336,11 @@ __global__ __launch_bounds__(64 * WAVES, 2) void k_prop_attention(AttnArgs a) { 
         }
         pack_p();
     };
-    auto pv = [&]() __attribute__((always_inline)) {  // O^T += V(t)^T P(t)^T from the fragments in registers
+    // O^T += V(t)^T P(t)^T from the fragments in registers (first_half_only: the weights of keys 32..63 are zero)
+    auto pv = [&](bool first_half_only = false) __attribute__((always_inline)) {
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
+        for (int kb = 0; kb < 2; ++kb) {
+            if (kb == 1 && first_half_only) break;
 #pragma unroll
             for (int p = 0; p < 2; ++p) {
                 att_s16x8 vf0, vf1;
@@ -348,6 +354,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void k_prop_attention(AttnArgs a) { 
                 o0 = AttMfma<TX>::run(vf0, pf[kb][p], o0);
                 o1 = AttMfma<TX>::run(vf1, pf[kb][p], o1);
             }
+        }
     };
     // One iteration = tile t (weights and V fragments in registers) is accumulated while tile t+1 (slot S after the
     // barrier) gets its scores and weights.
@@ -381,7 +388,9 @@ __global__ __launch_bounds__(64 * WAVES, 2) void k_prop_attention(AttnArgs a) { 
 #if ATT_PRIO == 1
         __builtin_amdgcn_s_setprio(1);
 #endif
-        scores(S, negm);
+        // the partly filled last tile with at most 32 keys in range: the second half of its scores is never computed
+        const bool half = masked && (t + 1) * ATT_BN + 32 >= a.Nk;
+        scores(S, negm, half);
         pv();
 #if ATT_PRIO == 1
         __builtin_amdgcn_s_setprio(0);
@@ -393,7 +402,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void k_prop_attention(AttnArgs a) { 
         v_fragments(S);
 #endif
 #if ATT_PRIO == 2 || ATT_PRIO == 4
-        __builtin_amdgcn_s_setprio(1);
+        if (!(BIAS && WAVES == 4)) __builtin_amdgcn_s_setprio(1);  // (that instance would spill: the builtin fences the scheduler)
 #endif
 #if !(ATT_ABL & 1)
 #pragma unroll
@@ -428,7 +437,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void k_prop_attention(AttnArgs a) { 
         const float lsum = att_add(att_add(c0s, c1s), att_add(c2s, c3s));
         pack_p();
 #if ATT_PRIO == 2 || ATT_PRIO == 3
-        __builtin_amdgcn_s_setprio(0);
+        if (!(BIAS && WAVES == 4)) __builtin_amdgcn_s_setprio(0);
 #endif
         l_run += lsum;
         bad = bad || !(lsum <= AttLimit<TX>::value);  // inf / NaN / too large: this pass is void (rerun below)
@@ -482,7 +491,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void k_prop_attention(AttnArgs a) { 
                 for (; t + 1 < ntiles; ++t) fast_step((t + 1) & 1, t, true);
             }
             for (; t + 1 < ntiles; ++t) slow_step(t);
-            pv();  // the last tile
+            pv((ntiles - 1) * ATT_BN + 32 >= a.Nk);  // the last tile (its keys 32..63 may all lie past the end)
         } else {
             for (; t + 1 < ntiles; ++t) helper_step(t);
         }
