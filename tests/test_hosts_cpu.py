@@ -74,3 +74,55 @@ def test_harness_builds_the_four_families():
         assert hasattr(mod, attr)
     with pytest.raises(ValueError):
         harness.build_model(harness.load_cfg(None, ["MODEL.MODEL_NAME", "SlowFast"]))
+
+
+def test_fold_decisions_of_the_block_glue():
+    """The host logic that decides whether a block's last Linear may accumulate onto the residual stream in place
+    (tome/patch/_common.py: _plain_mlp, foldable, finish_linear, mlp_residual) -- no kernel runs here."""
+    from tome.patch import _common as C
+
+    class Mlp(torch.nn.Module):
+        def __init__(self, act):
+            super().__init__()
+            self.fc1, self.act, self.fc2 = torch.nn.Linear(8, 16), act, torch.nn.Linear(16, 8)
+            self.drop = torch.nn.Dropout(0.0)
+
+        def forward(self, x):
+            return self.drop(self.fc2(self.act(self.fc1(x))))
+
+    plain = Mlp(torch.nn.GELU()).eval()
+    assert C._plain_mlp(plain)
+    assert not C._plain_mlp(Mlp(torch.nn.GELU(approximate="tanh")).eval())   # not the exact-erf form
+    assert not C._plain_mlp(Mlp(torch.nn.ReLU()).eval())
+    assert not C._plain_mlp(Mlp(torch.nn.GELU()).train())                    # dropout may be live
+    extra = Mlp(torch.nn.GELU()).eval()
+    extra.norm = torch.nn.LayerNorm(16)                                      # a child the fast path does not know
+    assert not C._plain_mlp(extra)
+
+    with torch.no_grad():
+        assert C.foldable(plain.fc2) is plain.fc2
+        assert C.foldable(plain.fc2, eval_mode=False) is None
+        assert C.foldable(torch.nn.Linear(4, 4, bias=False)) is None
+        assert C.foldable(torch.nn.Identity()) is None
+    assert C.foldable(plain.fc2) is None                                     # grad mode with trainable weights
+    frozen = Mlp(torch.nn.GELU()).eval().requires_grad_(False)
+    assert C.foldable(frozen.fc2) is frozen.fc2
+
+    # finish_linear without a folded bias is the plain residual (on CPU: x + linear(h)), and clears nothing it does not own
+    class Block(torch.nn.Module):
+        pass
+    blk = Block().eval()
+    x, h, info = torch.randn(2, 5, 8), torch.randn(2, 5, 16), {}
+    with torch.no_grad():
+        torch.testing.assert_close(C.finish_linear(blk, x, h, plain.fc2, info), x + plain.fc2(h))
+        # a folded bias that belongs to another Linear, or an MLP the fold was not made for, is refused loudly
+        info["_folded"] = (x, torch.nn.Linear(16, 8))
+        with pytest.raises(RuntimeError):
+            C.finish_linear(blk, x, h, plain.fc2, info)
+        info["_folded"] = (x, plain.fc2)
+        with pytest.raises(RuntimeError):
+            C.mlp_residual(blk, Mlp(torch.nn.ReLU()).eval(), x, torch.randn(2, 5, 8), info)
+        # a fold recorded for ANOTHER tensor is not this block's business: plain path
+        other = {"_folded": (torch.randn(2, 5, 8), plain.fc2)}
+        y = torch.randn(2, 5, 8)
+        torch.testing.assert_close(C.mlp_residual(blk, plain, x, y, other), x + plain(y))
