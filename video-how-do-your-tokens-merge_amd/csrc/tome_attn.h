@@ -139,8 +139,8 @@ template <typename TX> __device__ __forceinline__ short att_bits(float f) {
 #define ATT_PRIO 2  // s_setprio(1) while a wave runs the softmax of its step (exp, row sums, packing), 0 around its
                     // matrix instructions: the partner wave's MFMAs fill in behind.  Measured (tools/ab_lib.sh): 0 = none
                     // 725-734 / 821-825 TFLOP/s plain, 651 / 690 with the size bias at 128x12x1568 / x1472; 2 = 736-737 /
-                    // 830 and 665-667 / 710; 1 (priority around the MFMAs instead) 684 / 786; 3 (from the V-fragment
-                    // reads on) 726-728 / 781-792; 4 (exp only) 721-723 / 788-791; a static priority for one wave of
+                    // 830 and 665-667 / 710; tried and dropped: priority around the MFMAs instead 684 / 786; from the V-fragment
+                    // reads on 726-728 / 781-792; exp only 721-723 / 788-791; a static priority for one wave of
                     // each SIMD pair instead: no gain plain, -5...-8 % with the bias
 #endif
 #ifndef ATT_ABL
@@ -385,23 +385,14 @@ __global__ __launch_bounds__(64 * WAVES, 2) void k_prop_attention(AttnArgs a) { 
 #endif
         // (measured: a hand-placed issue order of this block -- every MFMA followed by the vector work that fits its
         // shadow, pinned by sched_barrier fences -- runs within 1 % of what the compiler makes of it)
-#if ATT_PRIO == 1
-        __builtin_amdgcn_s_setprio(1);
-#endif
         // the partly filled last tile with at most 32 keys in range: the second half of its scores is never computed
         const bool half = masked && (t + 1) * ATT_BN + 32 >= a.Nk;
         scores(S, negm, half);
         pv();
-#if ATT_PRIO == 1
-        __builtin_amdgcn_s_setprio(0);
-#endif
-#if ATT_PRIO == 3
-        __builtin_amdgcn_s_setprio(1);
-#endif
 #if !(ATT_ABL & 4)
         v_fragments(S);
 #endif
-#if ATT_PRIO == 2 || ATT_PRIO == 4
+#if ATT_PRIO == 2
         if (!(BIAS && WAVES == 4)) __builtin_amdgcn_s_setprio(1);  // (that instance would spill: the builtin fences the scheduler)
 #endif
 #if !(ATT_ABL & 1)
@@ -409,9 +400,6 @@ __global__ __launch_bounds__(64 * WAVES, 2) void k_prop_attention(AttnArgs a) { 
         for (int v = 0; v < 16; ++v) s0[v] = __builtin_amdgcn_exp2f(s0[v]);
 #pragma unroll
         for (int v = 0; v < 16; ++v) s1[v] = __builtin_amdgcn_exp2f(s1[v]);
-#endif
-#if ATT_PRIO == 4
-        __builtin_amdgcn_s_setprio(0);
 #endif
         if (masked) {  // the partly filled last tile: keys past the end weigh nothing
             const int key0 = (t + 1) * ATT_BN + 4 * hf;
@@ -436,7 +424,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void k_prop_attention(AttnArgs a) { 
         }
         const float lsum = att_add(att_add(c0s, c1s), att_add(c2s, c3s));
         pack_p();
-#if ATT_PRIO == 2 || ATT_PRIO == 3
+#if ATT_PRIO == 2
         if (!(BIAS && WAVES == 4)) __builtin_amdgcn_s_setprio(0);
 #endif
         l_run += lsum;
