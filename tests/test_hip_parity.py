@@ -1092,6 +1092,117 @@ def test_prop_attention_running_maximum_moves(growth, dtype, tol):
         assert float((out.float() - want).abs().max()) <= tol
 
 
+@pytest.mark.parametrize("waves", ["4", "8"])
+@pytest.mark.parametrize("case", _attn_fuzz_cases(24, 20261005), ids=lambda c: "B%dH%dN%d-%s-%s-%s" % c)
+def test_prop_attention_fuzz_each_workgroup_shape(case, waves, monkeypatch):
+    """The fuzz shapes again with the workgroup shape forced (TOME_ATTN_WAVES is read per call): 8-wave workgroups are
+    what the large launches of the benchmark run -- waves 4-7 half a barrier interval behind waves 0-3 -- and small
+    inputs only reach them this way."""
+    monkeypatch.setenv("TOME_ATTN_WAVES", waves)
+    test_prop_attention_fuzz(case)
+
+
+@pytest.mark.parametrize("waves", ["4", "8"])
+@pytest.mark.parametrize("N", [65, 96, 97, 128, 160, 161, 449, 480, 481, 1568])
+def test_prop_attention_tile_edges_each_workgroup_shape(N, waves, monkeypatch):
+    """Key counts around the 64-key tile with at most / more than 32 keys in the last tile (the half-tile shortcut),
+    one to many tiles, for both workgroup shapes, all three bias forms and the segmented form."""
+    from tome import _abi
+    monkeypatch.setenv("TOME_ATTN_WAVES", waves)
+    g = torch.Generator(device=DEV).manual_seed(N)
+    B, H = 2, 3
+    for dtype, tol in ((torch.bfloat16, 1e-2), (torch.float16, 2e-3)):
+        qkv = torch.randn(B, N, 3, H, 64, device=DEV, generator=g).to(dtype)
+        q, k, v = qkv.permute(2, 0, 3, 1, 4)
+        for mode in ("none", "bias", "skip"):
+            n = N - (1 if mode == "skip" else 0)
+            size = log_b = None
+            if mode != "none":
+                size = torch.randint(1, 30, (B, n, 1), device=DEV, generator=g).float()
+                log_b = size.log()[:, :, 0]
+            out = _abi.prop_attention(q, k, v, size, 0.125, bias_skip=(mode == "skip"))
+            want = _attn_reference(q, k, v, log_b, 0.125, mode == "skip")
+            assert float((out.float() - want).abs().max()) <= tol, (mode, dtype)
+    if N <= 161:  # segments of N keys each
+        F = 3
+        qkv = torch.randn(B, N * F, 3, H, 64, device=DEV, generator=g).bfloat16()
+        q, k, v = qkv.permute(2, 0, 3, 1, 4)
+        lb = torch.randint(1, 30, (B, N * F), device=DEV, generator=g).float().log()
+        y = _abi.prop_attention_segments(q, k, v, F, 0.125, log_bias=lb)
+        logits = (q.float() @ k.float().transpose(-1, -2)) * 0.125 + lb[:, None, None, :]
+        w = logits.reshape(B, H, N * F, F, N).softmax(-1)
+        want = torch.einsum("b h q f n, b h f n d -> b q f h d", w, v.float().reshape(B, H, F, N, 64))
+        assert float((y.float() - want.reshape(B, N * F, F, H * 64)).abs().max()) <= 1e-2
+
+
+@pytest.mark.parametrize("waves", ["4", "8"])
+@pytest.mark.parametrize("dtype,tol,jump", [(torch.bfloat16, 2e-2, 70.0), (torch.float16, 4e-3, 18.0),
+                                            (torch.float16, 4e-3, 70.0)])
+@pytest.mark.parametrize("N", [200, 224, 700])
+def test_prop_attention_rerun_path(N, dtype, tol, jump, waves, monkeypatch):
+    """The first pass keeps the reference point of tile 0 and is void when a row sum leaves the 16-bit format's
+    range; the workgroup then repeats the block on the general path.  Forced here: the logits of every query sit
+    near 0 in the first tile and `jump` (log2 units: > 60 for bf16, > 15 for fp16) higher from some later tile on --
+    the un-rescaled weights overflow, only the rerun gives finite, correct rows.  Plain, size-biased, TimeSformer's
+    bias_skip form and key segments; last tiles with <= 32 and > 32 keys; both workgroup shapes."""
+    from tome import _abi
+    monkeypatch.setenv("TOME_ATTN_WAVES", waves)
+    g = torch.Generator(device=DEV).manual_seed(N + int(jump))
+    B, H = 2, 3
+    direction = torch.randn(B, H, 1, 64, device=DEV, generator=g)
+    direction = direction / direction.norm(dim=-1, keepdim=True)
+    # q . k * scale * log2(e) = jump for the late keys: q = 8 d, k = a d -> 8 a / 8 * 1.4427 = jump
+    amp = jump / 1.4426950408889634
+    step = torch.zeros(1, 1, N, 1, device=DEV)
+    step[:, :, 100:] = amp  # from the second tile on
+    q = (8.0 * direction + 0.05 * torch.randn(B, H, N, 64, device=DEV, generator=g)).to(dtype)
+    k = (step * direction + 0.05 * torch.randn(B, H, N, 64, device=DEV, generator=g)).to(dtype)
+    v = torch.randn(B, H, N, 64, device=DEV, generator=g).to(dtype)
+    size = torch.randint(1, 9, (B, N, 1), device=DEV, generator=g).float()
+    for mode in ("none", "bias", "skip"):
+        sz = None if mode == "none" else (size if mode == "bias" else size[:, 1:])
+        out = _abi.prop_attention(q, k, v, sz, 0.125, bias_skip=(mode == "skip"))
+        want = _attn_reference(q, k, v, None if sz is None else sz.log()[:, :, 0], 0.125, mode == "skip")
+        assert torch.isfinite(out.float()).all(), mode
+        assert float((out.float() - want).abs().max()) <= tol, mode
+    # the naive single-reference computation does overflow on these inputs (the case is not vacuous)
+    s2 = (q.float() @ k.float().transpose(-1, -2)) * (0.125 * 1.4426950408889634)
+    first_max = s2[..., :64].amax(-1, keepdim=True)
+    lim = 60.0 if dtype == torch.bfloat16 else 15.0
+    assert float((s2 - first_max).amax()) > lim
+    # key segments (Motionformer): the jump inside every segment
+    F = 2
+    P = N // F
+    stepf = torch.zeros(1, 1, F, P, 1, device=DEV)
+    stepf[:, :, :, 70:] = amp
+    ks = (stepf.reshape(1, 1, F * P, 1) * direction + 0.05 * torch.randn(B, H, F * P, 64, device=DEV, generator=g)).to(dtype)
+    qs, vs = q[:, :, :F * P].contiguous(), v[:, :, :F * P].contiguous()
+    lb = size[:, :F * P, 0].log().contiguous()
+    y = _abi.prop_attention_segments(qs, ks, vs, F, 0.125, log_bias=lb)
+    logits = (qs.float() @ ks.float().transpose(-1, -2)) * 0.125 + lb[:, None, None, :]
+    w = logits.reshape(B, H, F * P, F, P).softmax(-1)
+    wantf = torch.einsum("b h q f n, b h f n d -> b q f h d", w, vs.float().reshape(B, H, F, P, 64))
+    assert torch.isfinite(y.float()).all()
+    assert float((y.float() - wantf.reshape(B, F * P, F, H * 64)).abs().max()) <= tol
+
+
+def test_prop_attention_large_launch_takes_eight_wave_workgroups():
+    """A launch of the benchmark's size class (B*H*blocks >= 1024: the dispatcher picks 8-wave workgroups by itself)
+    against the fp32 reference, per batch slice to bound the reference's memory."""
+    from tome import _abi
+    g = torch.Generator(device=DEV).manual_seed(5)
+    B, H, N = 16, 12, 1568
+    qkv = torch.randn(B, N, 3, H, 64, device=DEV, generator=g).bfloat16()
+    q, k, v = qkv.permute(2, 0, 3, 1, 4)
+    size = torch.randint(1, 9, (B, N, 1), device=DEV, generator=g).float()
+    for sz in (None, size):
+        out = _abi.prop_attention(q, k, v, sz, 0.125)
+        for b in range(0, B, 4):
+            want = _attn_reference(q[b:b + 4], k[b:b + 4], v[b:b + 4], None if sz is None else sz[b:b + 4].log()[:, :, 0],
+                                   0.125, False)
+            assert float((out[b:b + 4].float() - want).abs().max()) <= 1e-2
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 def test_gelu_erf_is_the_frameworks_gelu(dtype):
     """tome_gelu_erf (the MLP's activation inside the patched block) == torch's nn.GELU() bit for bit: same fp32

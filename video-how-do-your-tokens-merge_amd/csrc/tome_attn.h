@@ -149,6 +149,24 @@ template <typename TX> __device__ __forceinline__ short att_bits(float f) {
 
 template <int V> struct AttInt { static constexpr int value = V; };
 
+#ifdef ATT_DIAG
+// Diagnostic build only (tools/attn_diag.py; never the shipped library): every wave of the first ATT_DIAG_WGS
+// workgroups stamps the 100 MHz wall counter (s_memrealtime) at the phases of its query block; the stamps go to a
+// buffer of their own that nothing else reads.
+#define ATT_DIAG_WGS 8192
+#define ATT_DIAG_N 8
+__device__ unsigned long long g_att_stamps[ATT_DIAG_WGS * 8 * ATT_DIAG_N];
+#define ATT_STAMP(i)                                                                                         \
+    do {                                                                                                     \
+        if (blockIdx.x < ATT_DIAG_WGS) {                                                                     \
+            const unsigned long long st_ = __builtin_amdgcn_s_memrealtime();                                 \
+            if (lane == 0) g_att_stamps[((size_t)blockIdx.x * 8 + wave) * ATT_DIAG_N + (i)] = st_;            \
+        }                                                                                                    \
+    } while (0)
+#else
+#define ATT_STAMP(i)
+#endif
+
 template <typename TX, int WAVES, bool BIAS>
 __global__ __launch_bounds__(64 * WAVES, 2) void k_prop_attention(AttnArgs a) {  // two waves per SIMD either way
     constexpr int ATT_BM = 32 * WAVES;
@@ -160,6 +178,11 @@ __global__ __launch_bounds__(64 * WAVES, 2) void k_prop_attention(AttnArgs a) { 
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int col = lane & 31, hf = lane >> 5;
+    ATT_STAMP(0);  // entry
+#ifdef ATT_DIAG
+    if (blockIdx.x < ATT_DIAG_WGS && lane == 0)
+        g_att_stamps[((size_t)blockIdx.x * 8 + wave) * ATT_DIAG_N + 7] = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11));
+#endif
     const int qblocks = (a.N + ATT_BM - 1) / ATT_BM;
     // XCD-aware mapping: the query blocks of one (batch, head, segment) stream the same K/V -> same XCD (ids congruent
     // mod 8).  (Measured: persistent workgroups walking a run of items each are 3 % slower than this.)
@@ -196,6 +219,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void k_prop_attention(AttnArgs a) { 
         }
     }
 
+    ATT_STAMP(1);  // Q fragment requested / in registers
     att_f32x16 o0, o1, negm;
 #pragma unroll
     for (int v = 0; v < 16; ++v) o0[v] = o1[v] = negm[v] = 0.0f;
@@ -464,11 +488,13 @@ __global__ __launch_bounds__(64 * WAVES, 2) void k_prop_attention(AttnArgs a) { 
         stage_write(0);
         if (ntiles > 1) stage_load(1);
         __syncthreads();
+        ATT_STAMP(2);  // tile 0 in LDS
         // iterations t = 0 .. ntiles-2 bring in tile t+1; those with t+1 < nfull may take the fast form
         int t = 0;
         if (active) {
             general_softmax(0, 0);
             v_fragments(0);
+            ATT_STAMP(3);  // first tile's weights
             if (pass == 0) {
                 for (; t + 2 < nfull; t += 2) {  // t even: tile t+1 -> slot 1, tile t+2 -> slot 0, both full
                     fast_step(1, t, false);
@@ -479,6 +505,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void k_prop_attention(AttnArgs a) { 
                 for (; t + 1 < ntiles; ++t) fast_step((t + 1) & 1, t, true);
             }
             for (; t + 1 < ntiles; ++t) slow_step(t);
+            ATT_STAMP(4);  // tile loop done
             pv((ntiles - 1) * ATT_BN + 32 >= a.Nk);  // the last tile (its keys 32..63 may all lie past the end)
         } else {
             for (; t + 1 < ntiles; ++t) helper_step(t);
@@ -511,6 +538,11 @@ __global__ __launch_bounds__(64 * WAVES, 2) void k_prop_attention(AttnArgs a) { 
         const uint4 row16 = uint4{s0w[0], s1w[0], s0w[1], s1w[1]};
         if (qrow < a.N) *reinterpret_cast<uint4 *>(op + 8 * g) = row16;
     }
+    ATT_STAMP(5);  // stores issued
+#ifdef ATT_DIAG
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    ATT_STAMP(6);  // stores done
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------

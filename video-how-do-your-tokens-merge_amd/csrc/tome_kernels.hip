@@ -797,7 +797,8 @@ static int prop_attention_impl(const void *q, const void *k, const void *v, int 
     // queries per workgroup: 256 (eight waves share every staged K/V tile: staging costs 18 % with four) unless the
     // sequence is short.  (Measured: 5, 6 or 7 waves per workgroup, chosen to leave no part-empty last block, are
     // 10-30 % slower per block than eight -- uneven staging passes and SIMD load -- and lose more than they save.)
-    static const int waves_env = [] {
+    // (read per call, not cached: the tests force each workgroup shape on small inputs)
+    const int waves_env = [] {
         const char *e = getenv("TOME_ATTN_WAVES");
         int v = e ? atoi(e) : 0;
         return (v == 4 || v == 8) ? v : 0;
@@ -822,6 +823,16 @@ static int prop_attention_impl(const void *q, const void *k, const void *v, int 
 #undef ATT_LAUNCH
     return check_launch("k_prop_attention");
 }
+
+#ifdef ATT_DIAG
+// diagnostic build: the phase stamps of the last k_prop_attention launch (tools/attn_diag.py)
+extern "C" int tome_attn_diag_read(unsigned long long *host, int64_t count) {
+    if (count > (int64_t)ATT_DIAG_WGS * 8 * ATT_DIAG_N) count = (int64_t)ATT_DIAG_WGS * 8 * ATT_DIAG_N;
+    if (hipMemcpyFromSymbol(host, HIP_SYMBOL(g_att_stamps), count * sizeof(unsigned long long)) != hipSuccess)
+        return fail(TOME_ELAUNCH, "tome_attn_diag_read: copy failed");
+    return TOME_OK;
+}
+#endif
 
 extern "C" int tome_trajectory_mix(const void *q2, const void *k2, const void *val, int dtype, int64_t B, int64_t S,
                                    int64_t F, int64_t H, int64_t D, int64_t k_row_stride, int64_t v_row_stride,
