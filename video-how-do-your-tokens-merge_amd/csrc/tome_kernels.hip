@@ -30,6 +30,7 @@
 #include "tome_match.h"
 #include "tome_merge.h"
 #include "tome_attn.h"
+#include "tome_attn_stream.h"
 
 // ------------------------------------------------------------------------------------------------
 // host side: argument checks, workspace carving, launches
@@ -812,6 +813,31 @@ static int prop_attention_impl(const void *q, const void *k, const void *v, int 
     if (bh8 * qblocks > 0x7fffffffLL) return fail(TOME_EINVAL, "tome_prop_attention: grid too large");
     const dim3 grid((unsigned)(bh8 * qblocks));
     hipStream_t st = (hipStream_t)stream;
+    // Eight-wave launches with at least two key tiles run as persistent workgroups, one per CU, that keep the K/V
+    // pipeline going across query blocks (tome_attn_stream.h); TOME_ATTN_STREAM=0 keeps one workgroup per block
+    // (measurement switch, read per call)
+    const char *se = getenv("TOME_ATTN_STREAM");
+    const int64_t sn_max = 1 << 22;  // (the stream kernel keeps token offsets inside a tile / query block in 32 bits)
+    const bool sn_ok = a.q_sn < sn_max && a.k_sn < sn_max && a.v_sn < sn_max && a.o_sn < sn_max;
+    if (waves == 8 && Nk > ATT_BN && sn_ok && !(se && se[0] == '0')) {
+        static const int cus = [] {
+            int dev = 0, n = 0;
+            if (hipGetDevice(&dev) != hipSuccess ||
+                hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+                n = 256;
+            return n / 8 * 8;
+        }();
+        const int nitems = (int)(bh8 * qblocks);
+        const dim3 pgrid((unsigned)(nitems < cus ? nitems : cus));
+        if (dtype == TOME_BF16) {
+            if (log_size) hipLaunchKernelGGL((k_prop_attention_stream<bf16_t, true>), pgrid, dim3(512), 0, st, a, nitems);
+            else hipLaunchKernelGGL((k_prop_attention_stream<bf16_t, false>), pgrid, dim3(512), 0, st, a, nitems);
+        } else {
+            if (log_size) hipLaunchKernelGGL((k_prop_attention_stream<f16_t, true>), pgrid, dim3(512), 0, st, a, nitems);
+            else hipLaunchKernelGGL((k_prop_attention_stream<f16_t, false>), pgrid, dim3(512), 0, st, a, nitems);
+        }
+        return check_launch("k_prop_attention_stream");
+    }
 #define ATT_LAUNCH(TX, BI)                                                                        \
     if (waves == 8) hipLaunchKernelGGL((k_prop_attention<TX, 8, BI>), grid, dim3(512), 0, st, a); \
     else hipLaunchKernelGGL((k_prop_attention<TX, 4, BI>), grid, dim3(256), 0, st, a);
