@@ -63,6 +63,8 @@ def parse():
     ap.add_argument("--also-quick", action="store_true", help="`also` at an eighth of the batch and few iterations (tests)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to "
                     "rehearse N>1 on a one-GPU box)")
+    ap.add_argument("--force-group", action="store_true", help="form the torch.distributed group at N=1 too (a group of "
+                    "one: RCCL initialisation and the job's collectives run on a single GPU; tests/test_launch_gpu.py)")
     return ap.parse_args()
 
 
@@ -157,8 +159,38 @@ def measure_kernels(batch: int, t0: int, r: int, dev, reps: int = 10, isolated: 
     they are launched on (torch's current stream).  Returns per-kernel totals over one forward's launches.
     isolated=False: only the three matching stages (timed inside tome_match_keys); the two streaming kernels are then
     timed inside the forward by LaunchTimer."""
+    import ctypes
     from tome import _abi
     L = _abi.lib()
+    # the stage events live in the MEASUREMENT build of the library (csrc/build.py builds lib/libtome_hip_prof.so
+    # with -DTOME_PROFILE_HOOKS beside the product library; the product ABI has no such entry points).  It is bound
+    # here, swapped in for the matching calls of this function only, and never touches the forward that is timed.
+    prof_path = os.path.join(os.path.dirname(_abi.LIB_PATH), "libtome_hip_prof.so")
+    P = _abi.bind(prof_path)
+    P.tome_profile_enable.restype = ctypes.c_int
+    P.tome_profile_enable.argtypes = [ctypes.c_int]
+    P.tome_profile_read.restype = ctypes.c_int
+    P.tome_profile_read.argtypes = [ctypes.c_void_p, ctypes.c_int]
+
+    def profile_read():
+        buf = (ctypes.c_float * 3)()
+        assert P.tome_profile_read(buf, 3) == 0
+        return [float(v) for v in buf]
+
+    def profiled_match(keys, re, reps):
+        acc, plan = [0.0, 0.0, 0.0], None
+        _abi._lib = P
+        try:
+            assert P.tome_profile_enable(reps) == 0  # every stage kernel is launched `reps` times between events
+            for i in range(3):
+                plan = _abi.match_keys(keys, re)
+                ms = profile_read()
+                if i >= 1:
+                    acc = [a + b / 2 for a, b in zip(acc, ms)]
+            assert P.tome_profile_enable(0) == 0
+        finally:
+            _abi._lib = L
+        return plan, acc
     sched = [(t, re) for t, re in token_schedule(t0, r, LAYERS) if re > 0]
     g = torch.Generator(device=dev).manual_seed(7)
     stats = {
@@ -181,15 +213,7 @@ def measure_kernels(batch: int, t0: int, r: int, dev, reps: int = 10, isolated: 
         qkv = torch.randn(batch, t, 3, HEADS, HEAD_DIM, device=dev, generator=g).bfloat16()
         keys = qkv.permute(2, 0, 3, 1, 4)[1]
         # --- matching: per-stage events recorded inside tome_match_keys
-        _abi.profile_enable(reps)  # every stage kernel is launched `reps` times back to back between events
-        acc = [0.0, 0.0, 0.0]
-        plan = None
-        for i in range(3):
-            plan = _abi.match_keys(keys, re)
-            ms = _abi.profile_read()
-            if i >= 1:
-                acc = [a + b / 2 for a, b in zip(acc, ms)]
-        _abi.profile_enable(0)
+        plan, acc = profiled_match(keys, re, reps)
         t1, t2 = (t + 1) // 2, t // 2
         for name, ms in zip(("k_unit_rows_heads", "k_scores_rowmax", "k_rank_select"), acc):
             stats[name]["ms"] += ms
@@ -538,7 +562,9 @@ def worker(args):
     dev_index = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
-    launch.init_process_group(args.backend, dev)  # "nccl" is RCCL on ROCm; no-op at N=1
+    # "nccl" is RCCL on ROCm; a no-op at N=1 unless --force-group (a group of one: RCCL initialised, the collectives run)
+    launch.init_process_group(args.backend, dev, force=args.force_group)
+    grouped = dist.is_available() and dist.is_initialized()
 
     import tome
     from tome import _abi
@@ -593,19 +619,19 @@ def worker(args):
         for _ in range(args.warmup):
             step()
         counts.zero_()
-        if world > 1:
+        if grouped:
             dist.barrier()
         torch.cuda.synchronize()
         t_start = time.perf_counter()
         for _ in range(args.steps):
             step()
-        all_reduce_counts(counts)  # the one collective: top-1 / top-5 / clip counts over xGMI (no-op at N=1)
+        all_reduce_counts(counts)  # the one collective: top-1 / top-5 / clip counts over xGMI (no-op without a group)
         torch.cuda.synchronize()
-        if world > 1:
+        if grouped:
             dist.barrier()
         elapsed = time.perf_counter() - t_start
     el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
+    if grouped:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el.item())
     census = launch.census(dev)  # ranks that answered + the device index of each (collective: every rank calls it)
@@ -624,7 +650,8 @@ def worker(args):
             "n_gpus": world,
             "ranks_seen": census["ranks_seen"],
             "rank_devices": census["devices"],
-            "backend": ("rccl" if args.backend == "nccl" else args.backend) if world > 1 else None,
+            "backend": ("rccl" if args.backend == "nccl" else args.backend) if grouped else None,
+            "process_group": bool(grouped),
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3),

@@ -293,16 +293,18 @@ int tome_row_map(int64_t n, int64_t T, int64_t r, int distill_token, const int64
 int tome_source_init(int64_t n, int64_t T, int64_t r, int distill_token, int drop, const int32_t *row_map,
                      float *source_out, tome_stream_t stream);
 
+#ifdef TOME_PROFILE_HOOKS
 /*
- * Measurement aid (bench.py): tome_profile_enable(reps > 0) makes tome_match on the calling thread record
- * HIP events between its stages on the caller's stream and launch every stage kernel `reps` times back to
- * back (the kernels are pure functions of their inputs, results are unchanged); tome_profile_read waits for
- * the last profiled call and returns the milliseconds PER LAUNCH of the stages {unit vectors,
- * similarity+row max, rank+select}.  Events are created by tome_profile_enable, never inside a launch
- * path; tome_profile_enable(0) switches it off.  No reference counterpart.
+ * MEASUREMENT BUILD ONLY (lib/libtome_hip_prof.so, compiled with -DTOME_PROFILE_HOOKS; not part of the product
+ * ABI, not in libtome_hip.so): tome_profile_enable(reps > 0) makes tome_match on the calling thread record HIP
+ * events between its stages on the caller's stream and launch every stage kernel `reps` times back to back (the
+ * kernels are pure functions of their inputs, results are unchanged); tome_profile_read waits for the last
+ * profiled call and returns the milliseconds PER LAUNCH of the stages {unit vectors, similarity+row max,
+ * rank+select}.  bench.py's stage-timing leg is the only caller.  No reference counterpart.
  */
 int tome_profile_enable(int on);
 int tome_profile_read(float *stage_ms, int max_stages);
+#endif
 
 #ifdef __cplusplus
 }

@@ -11,10 +11,15 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _declared_symbols():
+def _declared_symbols(measurement_build=False):
+    """Entry points include/tome_hip.h declares: the product ABI, or (measurement_build) what its
+    `#ifdef TOME_PROFILE_HOOKS` section adds for lib/libtome_hip_prof.so."""
     text = open(os.path.join(ROOT, "include", "tome_hip.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(tome_[a-z_]+)\s*\(", text)))
+    hooks = re.findall(r"#ifdef TOME_PROFILE_HOOKS(.*?)#endif", text, flags=re.S)
+    product = re.sub(r"#ifdef TOME_PROFILE_HOOKS.*?#endif", "", text, flags=re.S)
+    pick = "".join(hooks) if measurement_build else product
+    return sorted(set(re.findall(r"\b(tome_[a-z_]+)\s*\(", pick)))
 
 
 def test_header_symbols_are_exported():
@@ -26,6 +31,22 @@ def test_header_symbols_are_exported():
         assert hasattr(L, name), f"{name} declared in include/tome_hip.h but not exported"
     assert set(names) == set(_abi.SYMBOLS)
     assert L.tome_abi_version() == _abi.ABI_VERSION
+
+
+def test_measurement_hooks_live_in_their_own_library_only():
+    """tome_profile_enable / tome_profile_read (stage events + repeated launches for bench.py's roofline figures) are
+    not part of the product: libtome_hip.so does not export them, lib/libtome_hip_prof.so (-DTOME_PROFILE_HOOKS,
+    bound by bench.py's stage-timing leg alone) exports them beside the whole product ABI."""
+    from tome import _abi
+    hooks = _declared_symbols(measurement_build=True)
+    assert hooks == ["tome_profile_enable", "tome_profile_read"]
+    product = ctypes.CDLL(_abi.LIB_PATH)
+    prof = ctypes.CDLL(os.path.join(os.path.dirname(_abi.LIB_PATH), "libtome_hip_prof.so"))
+    for name in hooks:
+        assert not hasattr(product, name) and hasattr(prof, name), name
+        assert name not in _abi.SYMBOLS
+    for name in _declared_symbols():
+        assert hasattr(prof, name), name
 
 
 def test_effective_r_matches_reference_clamp():

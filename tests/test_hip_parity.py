@@ -251,6 +251,34 @@ def test_merge_source_first_layer_without_identity(n, T, r, cls, distill):
     assert peak < 1.5 * want.numel() * 4 + (1 << 20), (peak, want.numel() * 4, before)  # no [n,T,T] identity beside the result
 
 
+def test_merge_source_first_layer_hybrid_keeps_killed_destinations():
+    """A hybrid matching (merge.py:274-352) zeroes a destination whose incoming edge scores below the threshold
+    before the amax (merge.py:326-331): in the first layer's source matrix that destination's OWN column is 0.
+    merge_source(source=None) must reproduce that (== merge(eye, "max") of the same closure) -- the one-hot shortcut
+    of the plain matching would write a 1 there.  The threshold sits inside the selected edges' scores, so some
+    destinations are killed and some are not (asserted)."""
+    tm = _tome()
+    n, T, r = 3, 96, 20
+    metric = dev(synth.normal_like((n, T, 16), 4242))
+    plain, _ = tm.bipartite_soft_matching(metric, r)
+    nm = plain.plan.node_max if getattr(plain.plan, "node_max", None) is not None else None
+    if nm is None:
+        from tome import _abi
+        nm = _abi.match(metric, r, False, False, want_node_max=True).node_max
+    sel = torch.sort(nm, dim=1, descending=True).values[:, :r]
+    thr = float(sel[:, r // 2].mean())  # about half of the selected edges lie below it
+    merge, _ = tm.bipartite_soft_matching_hybrid(metric, r, threshold=thr)
+    assert merge.plan.edge_keep is not None
+    keep = merge.plan.edge_keep.bool()
+    assert bool(keep.any()) and bool((~keep).any()), "threshold does not split the selected edges"
+    eye = torch.eye(T, device=DEV)[None].expand(n, T, T).contiguous()
+    want = merge(eye, mode="max")
+    got = tm.merge_source(merge, torch.zeros(n, T, 1, device=DEV), None)
+    assert torch.equal(got, want)
+    # and it differs from the plain matching's source exactly in the killed destinations' own columns
+    assert float(want.sum()) < float(tm.merge_source(plain, torch.zeros(n, T, 1, device=DEV), None).sum())
+
+
 def test_random_merge_uses_given_scores():
     """random_merge / random_drop draw torch.rand scores (merge.py:54-57); the selection from a given
     score matrix must equal the oracle's."""
@@ -558,25 +586,6 @@ def test_fuzz_against_oracle(case):
         assert torch.equal(got.cpu(), torch.from_numpy(oracle.merge(plan, host(x), mode)).to(dtype)), mode
     back = unmerge(xo)
     assert torch.equal(back.cpu(), torch.from_numpy(oracle.unmerge(plan, host(xo))).to(dtype)), "unmerge"
-
-
-def test_unused_variants_shapes():
-    """kth_ / random_bipartite_soft_matching (merge.py:105-212; no patch calls them): token counts, conservation
-    under 'sum', unmerge shape -- and they refuse CPU tensors like the rest of the package."""
-    tm = _tome()
-    from tome._abi import TomeHipError
-    x = torch.randn(2, 30, 8, device=DEV)
-    merge, unmerge = tm.kth_bipartite_soft_matching(x, 3)
-    out = merge(x, mode="sum")
-    assert out.shape == (2, 10, 8) and torch.allclose(out.sum(1), x.sum(1), atol=1e-4)
-    assert unmerge(merge(x)).shape == x.shape
-    torch.manual_seed(1)
-    merge, unmerge = tm.random_bipartite_soft_matching(x, 7)
-    out = merge(x, mode="sum")
-    assert out.shape == (2, 23, 8) and torch.allclose(out.sum(1), x.sum(1), atol=1e-4)
-    assert unmerge(merge(x)).shape == x.shape
-    with pytest.raises(TomeHipError):
-        tm.kth_bipartite_soft_matching(torch.randn(1, 8, 4), 2)
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.bfloat16, 2 ** -7), (torch.float16, 2 ** -10)])

@@ -98,7 +98,10 @@ def _patched(meta, dtype=torch.float32):
     tome, model, patch = _build(meta)
     if meta.get("duplicate"):
         getattr(tome.patch, "duplicate_" + meta["host"])(model, *meta["duplicate"])
-    patch(model, prop_attn=meta["prop_attn"])
+    if meta.get("head_aggregation"):
+        patch(model, prop_attn=meta["prop_attn"], head_aggregation=meta["head_aggregation"])
+    else:
+        patch(model, prop_attn=meta["prop_attn"])
     return tome, model.to(dtype)
 
 
@@ -134,7 +137,12 @@ def test_patched_model_matches_reference(meta, monkeypatch):
     np.testing.assert_array_equal(model._tome_info["size"].cpu().numpy(), z["size"])
     np.testing.assert_allclose(out.cpu().numpy(), z["logits"], atol=2e-4, rtol=1e-4)
     head_dim = meta["cfg"]["embed_dim"] // meta["cfg"]["num_heads"]
-    if head_dim == 64:
+    if head_dim == 64 and meta.get("head_aggregation") == "concat":
+        # the metric is the heads' keys side by side (videomae.py:74-75): a strided [B, N, H*64] view of the qkv buffer
+        # handed to tome_match as it lies there
+        assert calls.n["match"] == len(plans) and calls.n["match_keys"] == 0, calls.n
+        assert all(s[2] == meta["cfg"]["embed_dim"] for s, _ in plans)
+    elif head_dim == 64:
         # the keys were averaged over the heads inside the matching kernel, never as a torch tensor
         assert calls.n["match_keys"] == len(plans) and calls.n["match"] == 0, calls.n
     if meta.get("duplicate"):
@@ -144,7 +152,7 @@ def test_patched_model_matches_reference(meta, monkeypatch):
 
 
 _HD64 = [m for m in G.manifest()["models"] if m["cfg"]["embed_dim"] // m["cfg"]["num_heads"] == 64]
-BF16_LOGIT_TOL = 0.10  # of the largest |logit| of the fixture; see the docstring below
+BF16_LOGIT_TOL = 0.08  # of the largest |logit| of the fixture (measured: 0.4 % .. 5.3 %); see the docstring below
 
 
 @pytest.mark.parametrize("meta", _HD64, ids=lambda m: m["name"])
@@ -180,7 +188,10 @@ def test_production_path_bf16_against_reference_fixture(meta, monkeypatch):
 
 def _assert_production_calls(calls, meta, n_layers):
     assert calls.n["prop_attention"] > 0 and calls.n["add_layernorm"] > 0, calls.n
-    assert calls.n["match_keys"] == n_layers and calls.n["match"] == 0, calls.n
+    if meta.get("head_aggregation") == "concat":
+        assert calls.n["match"] == n_layers and calls.n["match_keys"] == 0, calls.n
+    else:
+        assert calls.n["match_keys"] == n_layers and calls.n["match"] == 0, calls.n
     if meta["host"] == "motionformer":
         assert calls.n["trajectory_mix"] > 0, calls.n
     if not meta.get("duplicate"):  # (a duplicate block only attends and merges: no LayerNorm behind that merge)
@@ -217,6 +228,10 @@ def _check_layer0_and_logits(meta, z, plans32, plans16, out16):
     print(f"{meta['name']}: bf16 score noise {noise:.2e}; {checked_sets}/{want_src.shape[0]} source sets and "
           f"{checked_dst}/{want_src.size} destinations above it, all equal to the reference")
     assert checked_dst > 0, "no layer-0 decision lies above the bf16 noise: the fixture does not test this path"
+    if meta.get("l0_set_gap"):
+        # these fixtures' clips were chosen with a layer-0 r-boundary gap of >= 1e-2 in every group (the generator's
+        # l0_set_gap): every group's source SET is then above the 16-bit noise and has been compared
+        assert checked_sets == want_src.shape[0], (checked_sets, noise, meta["l0_set_gap"])
     ref = z["logits"]
     err = np.abs(out16.float().cpu().numpy() - ref).max()
     print(f"{meta['name']}: bf16 logits max |diff| {err:.3e} (largest |logit| {np.abs(ref).max():.3e})")
@@ -399,6 +414,93 @@ def test_graphed_forward_replays_the_merge_path():
     got_a = fwd([a]).clone()
     assert torch.equal(got_b, want_b) and torch.equal(got_a, want_a)
     assert not torch.equal(got_a, got_b)
+
+
+def _partition_of(source: torch.Tensor) -> np.ndarray:
+    """tests/golden/generate_models.py canonical_partition on the device: [n, T, T0] 0/1 -> [n, T0] smallest member of
+    every original token's merged group (free of the order of the merged rows)."""
+    n, T, T0 = source.shape
+    ids = torch.arange(T0, device=source.device).view(1, 1, T0).expand(n, T, T0)
+    first = torch.where(source > 0.5, ids, torch.full_like(ids, T0)).min(-1).values
+    owner = (source > 0.5).float().transpose(1, 2) @ first.float().unsqueeze(-1)
+    return owner[..., 0].round().cpu().numpy().astype(np.int16)
+
+
+def test_config0_videomae_b_full_size_against_the_reference(monkeypatch):
+    """BASELINE.json configs[0] AT FULL SIZE against the REAL reference (tests/golden/generate_models.py emit_config0:
+    tome/patch/videomae.py over slowfast's VideoMAE-B, 2 clips of 16x224x224, fill_parameters weights, fp32, r = 8,
+    CPU, trace_source on).  The fixture's clips were chosen so that in all 12 layers the r-boundary and the selected
+    rows' top-2 gaps exceed 2e-5 in fp64 (they are 6e-5 .. 2.6e-4), two orders above what fp32 evaluation moves such
+    cosines: given its INPUT ORDER, every merge of a layer is defined.  What stays open is the ORDER in which a layer
+    emits its ~770 unmerged rows per clip (sorted by row maxima that lie 1e-8 .. 1e-5 apart: the reference's unstable
+    argsort over fp32 values that differ between any two BLAS), and that order decides which tokens are even (sources)
+    and odd (destinations) in the NEXT layer -- so from the second or third layer on the reference itself would merge
+    other tokens on another machine.  Hence:
+      * tokens per layer and r_eff exactly; layer 0's src_idx / dst_idx exactly, unm_idx exactly at the positions the
+        fixture certifies (1049 of 1552; the rest as a set); the partition of the 1568 original tokens into merged
+        groups after layer 0 exactly (trace_source through tome_source_init / merge(., "max"), compared in the
+        order-free form of generate_models.canonical_partition);
+      * later layers: the share of original tokens whose merged group equals the reference's is printed per layer
+        (measured: identical through layer 1, then 99.7 % falling to 91.9 % after layer 11) and must stay >= 90 %;
+        sizes sum to 1568 per clip;
+      * logits within 0.5 % of the largest |logit| (4.8): measured 8.4e-3 = 0.18 % -- fp32 GEMMs and attention on
+        different BLAS / summation orders through 12 layers, plus the legitimately different late merges (92 % of the
+        tokens end in the reference's group; the others were merged with a near-identical neighbour instead).
+    The same clips in bf16 through the production kernels: token trace exact, logits within BF16_LOGIT_TOL of the
+    reference's largest logit."""
+    meta = G.manifest()["config0"]
+    assert meta["certified"]
+    z = np.load(os.path.join(G.GOLDEN, "models_config0_videomae_b.npz"))
+    tome, H = _hosts()
+    cfg = dict(meta["cfg"])
+    model = H["videomae"].VideoMAE(num_frames=cfg.pop("all_frames"), num_classes=cfg.pop("num_classes"),
+                                   tubelet_size=cfg.pop("tubelet_size"), **cfg)
+    names = synth.fill_parameters(model, meta["weight_seed"])
+    assert set(names) == set(meta["param_names"])
+    model = model.to(DEV).eval()
+    tome.patch.videomae(model, prop_attn=False, trace_source=True)
+    clip = _clip(meta)
+    # the source matrix after every layer
+    from tome.patch import _common
+    parts = []
+    real_ms = _common.merge_source
+
+    def spy_source(merge, x, source=None):
+        out = real_ms(merge, x, source)
+        parts.append(_partition_of(out))
+        return out
+    monkeypatch.setattr(_common, "merge_source", spy_source)
+    out, plans = _trace(tome, model, clip, meta["r"])
+    assert [s[1] for s, _ in plans] == meta["tokens"] and [p.r for _, p in plans] == meta["r_eff"]
+    p0 = plans[0][1]
+    np.testing.assert_array_equal(p0.src_idx.cpu().numpy()[..., 0], z["L0_src"])
+    np.testing.assert_array_equal(p0.dst_idx.cpu().numpy()[..., 0], z["L0_dst"])
+    got_unm, want_unm, ok = p0.unm_idx.cpu().numpy()[..., 0], z["L0_unm"].astype(np.int64), z["L0_unm_certified"]
+    np.testing.assert_array_equal(got_unm[ok], want_unm[ok])
+    np.testing.assert_array_equal(np.sort(got_unm, 1), np.sort(want_unm, 1))
+    assert len(parts) == len(meta["tokens"])
+    np.testing.assert_array_equal(parts[0], z["partitions"][0], err_msg="merged groups after layer 0")
+    agree = [float((got == z["partitions"][layer]).mean()) for layer, got in enumerate(parts)]
+    exact = next((i for i, a in enumerate(agree) if a < 1.0), len(agree))
+    print(f"config0 full size fp32: merged groups identical to the reference's through layer {exact - 1}; share of "
+          f"original tokens with the same group per layer: {[round(a, 4) for a in agree]}")
+    assert min(agree) >= 0.9, agree
+    sizes = model._tome_info["size"].cpu().numpy()[..., 0]
+    assert sizes.shape == z["size"].shape[:2] and (sizes.sum(1) == 1568.0).all() and (z["size"].sum((1, 2)) == 1568.0).all()
+    err = float(np.abs(out.cpu().numpy() - z["logits"]).max())
+    print(f"config0 full size fp32: logits max |diff| {err:.3e} (largest |logit| {np.abs(z['logits']).max():.3e})")
+    assert err <= 5e-3 * float(np.abs(z["logits"]).max()), err
+    # ---- the same clips as the benchmark runs them: bf16, every fused kernel on
+    monkeypatch.setattr(_common, "merge_source", real_ms)
+    model16 = H["videomae"].VideoMAE(num_frames=16, num_classes=400, tubelet_size=2, **cfg)
+    synth.fill_parameters(model16, meta["weight_seed"])
+    model16 = model16.to(DEV).to(torch.bfloat16).eval()
+    tome.patch.videomae(model16, prop_attn=False)
+    out16, plans16 = _trace(tome, model16, clip.bfloat16(), meta["r"])
+    assert [s[1] for s, _ in plans16] == meta["tokens"]
+    err16 = float(np.abs(out16.float().cpu().numpy() - z["logits"]).max())
+    print(f"config0 full size bf16: logits max |diff| {err16:.3e}")
+    assert err16 <= BF16_LOGIT_TOL * float(np.abs(z["logits"]).max()), err16
 
 
 def test_config0_videomae_b_fp32_vs_cpu_port():

@@ -37,10 +37,15 @@ for k, cs in agg.items():
             "issue-stalled (SQ_WAIT_INST_ANY)": round(m.get("SQ_WAIT_INST_ANY", 0) / wc, 3),
             "VALU active (SQ_ACTIVE_INST_VALU)": round(m.get("SQ_ACTIVE_INST_VALU", 0) / wc, 3),
         }
-    busy = m.get("SQ_BUSY_CU_CYCLES")
-    if busy and m.get("SQ_VALU_MFMA_BUSY_CYCLES"):
-        # SQ_BUSY_CU_CYCLES: quad-cycles summed over CUs; the matrix pipes of a CU's 4 SIMDs can each be busy
-        o["mfma_pipe_busy_fraction"] = round(m["SQ_VALU_MFMA_BUSY_CYCLES"] / (busy * 4.0 * 4.0), 3)
+    if m.get("GRBM_GUI_ACTIVE") and m.get("SQ_VALU_MFMA_BUSY_CYCLES"):
+        # SQ_VALU_MFMA_BUSY_CYCLES counts cycles per SIMD (32 per v_mfma_f32_32x32x16), summed over the chip's SIMDs;
+        # the cycles available to them are (GRBM_GUI_ACTIVE summed over the 8 XCDs / 8) x 1024 SIMDs.  (Round 2's
+        # version of this script divided by SQ_BUSY_CU_CYCLES x 16 and printed 0.089 for a pipe that was 33 % busy.)
+        cycles = m["GRBM_GUI_ACTIVE"] / 8.0
+        o["shader_cycles_per_launch"] = round(cycles)
+        if o.get("avg_launch_us_under_pmc"):
+            o["clock_ghz_under_pmc"] = round(cycles / o["avg_launch_us_under_pmc"] / 1e3, 3)
+        o["mfma_pipe_busy_fraction"] = round(m["SQ_VALU_MFMA_BUSY_CYCLES"] / (cycles * 1024.0), 3)
         o["mfma_coexec_with_valu_fraction_of_mfma_busy"] = round(
             m.get("SQ_VALU_MFMA_COEXEC_CYCLES", 0) / m["SQ_VALU_MFMA_BUSY_CYCLES"], 3)
     if m.get("SQ_INSTS_MFMA"):

@@ -64,8 +64,11 @@ extern "C" int64_t tome_effective_r(int64_t T, int64_t r, int class_token, int d
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
-// Optional per-stage timing of tome_match (bench.py's roofline figures): events are created when
-// profiling is switched on, never inside a launch path.
+// Per-stage timing of tome_match for bench.py's roofline figures: MEASUREMENT BUILD ONLY (-DTOME_PROFILE_HOOKS ->
+// lib/libtome_hip_prof.so, loaded by bench.py's stage-timing leg alone; csrc/build.py).  The product library carries
+// neither the entry points nor the repeated launches.
+#ifdef TOME_PROFILE_HOOKS
+// Events are created when profiling is switched on, never inside a launch path.
 #define PROF_EVENTS 4
 static thread_local struct {
     bool on = false;
@@ -106,6 +109,14 @@ extern "C" int tome_profile_read(float *stage_ms, int max_stages) {
     }
     return TOME_OK;
 }
+
+static inline int prof_reps_now() { return g_prof.on ? g_prof.reps : 1; }
+static inline void prof_done(int rc) { g_prof.valid = g_prof.on && rc == TOME_OK; }
+#else
+static inline void prof_mark(int, hipStream_t) {}
+static inline int prof_reps_now() { return 1; }
+static inline void prof_done(int) {}
+#endif
 
 #ifdef TOME_DIAG_CLOCK
 // diagnostic build: in-kernel clock of the last k_scores_rowmax launch = sum(cycles) / sum(100 MHz ticks) over
@@ -190,7 +201,7 @@ static int match_tail(const MatchWs &w, int64_t n, int64_t T, int64_t re, int cl
                       int64_t *src_idx, int64_t *dst_idx, int64_t *unm_idx, float *node_max, int32_t *row_map,
                       hipStream_t st) {
     const int T1 = (int)((T + 1) / 2), T2 = (int)(T / 2);
-    const int prof_reps = g_prof.on ? g_prof.reps : 1;
+    const int prof_reps = prof_reps_now();
     // 2. similarity + row max/argmax: one single-wave workgroup per (group, A tile, j-part); the B tiles are
     // split into WJ parts so that the launch has >= ~6 waves per SIMD (1024 SIMDs) whatever the batch
     static const long target_waves = [] {
@@ -220,7 +231,7 @@ static int match_tail(const MatchWs &w, int64_t n, int64_t T, int64_t re, int cl
     for (int rep = 0; rep < prof_reps && rc == TOME_OK; ++rep)
         rc = launch_select(w, WJ, true, n, T, re, class_token, distill_token, src_idx, dst_idx, unm_idx, node_max, row_map, st);
     prof_mark(3, st);
-    g_prof.valid = g_prof.on && rc == TOME_OK;
+    prof_done(rc);
     return rc;
 }
 extern "C" int tome_match(const void *metric, int dtype, int64_t n, int64_t T, int64_t D, int64_t stride_n,
@@ -246,7 +257,7 @@ extern "C" int tome_match(const void *metric, int dtype, int64_t n, int64_t T, i
     const bool fast = (D % 8 == 0) && (((uintptr_t)metric) % 16 == 0) && ((stride_n * es) % 16 == 0) &&
                       ((stride_t * es) % 16 == 0);
     bool launched = false;
-    const int prof_reps = g_prof.on ? g_prof.reps : 1;
+    const int prof_reps = prof_reps_now();
     for (int rep = 0; rep < prof_reps; ++rep) {
     launched = false;
 #define UNIT_FAST(TY, NCH)                                                                                    \
@@ -322,7 +333,7 @@ extern "C" int tome_match_keys(const void *keys, int dtype, int64_t n, int64_t H
     hipStream_t st = (hipStream_t)stream;
     const MatchWs w = carve(workspace, n, T, D);
     prof_mark(0, st);
-    const int prof_reps = g_prof.on ? g_prof.reps : 1;
+    const int prof_reps = prof_reps_now();
     const unsigned nb = (unsigned)((n * T + 31) / 32);
     for (int rep = 0; rep < prof_reps; ++rep) {
         switch (dtype) {

@@ -150,9 +150,14 @@ def _setup(cfg, dtype: str):
     rank, local, world = launch.check_world(cfg.NUM_GPUS * cfg.NUM_SHARDS)
     if not torch.cuda.is_available():
         raise SystemExit("the merge path has no CPU implementation: an MI355X is required")
+    backend = os.environ.get("TOME_DIST_BACKEND", getattr(cfg, "DIST_BACKEND", "nccl"))
+    if backend == "nccl" and world > 1 and int(os.environ.get("LOCAL_WORLD_SIZE", world)) > torch.cuda.device_count():
+        # several ranks on one GPU hang or fail inside RCCL instead of saying so
+        raise SystemExit(f"{os.environ.get('LOCAL_WORLD_SIZE', world)} ranks on this node but {torch.cuda.device_count()} GPU(s): "
+                         "RCCL needs one GPU per rank (TOME_DIST_BACKEND=gloo shares a GPU for a dry run)")
     dev = torch.device("cuda", local % torch.cuda.device_count())
     torch.cuda.set_device(dev)
-    launch.init_process_group(os.environ.get("TOME_DIST_BACKEND", getattr(cfg, "DIST_BACKEND", "nccl")), dev)
+    launch.init_process_group(backend, dev)
     torch.manual_seed(cfg.RNG_SEED)
     model = build_model(cfg).to(dev).to(_DTYPES[dtype]).eval()
     return model, dev, rank, world
@@ -262,6 +267,12 @@ def _launch(rank_fn, argv) -> dict:
     n = int(cfg.NUM_GPUS) * int(cfg.NUM_SHARDS)
     if launch.under_launcher() or n <= 1:
         return rank_fn(argv)
+    if int(cfg.NUM_SHARDS) > 1:
+        # the reference starts NUM_GPUS ranks PER SHARD (machine) with rank = SHARD_ID * NUM_GPUS + local
+        # (slowfast/utils/misc.py:414-428); spawning all NUM_GPUS * NUM_SHARDS ranks here would stack them on this one
+        # node's GPUs.  Several nodes take an external launcher (torch.distributed.run --nnodes ...).
+        raise SystemExit("NUM_SHARDS > 1: start one launcher per node (torch.distributed.run --nnodes NUM_SHARDS "
+                         "--nproc-per-node NUM_GPUS ...); the self-spawn covers one node")
     with tempfile.TemporaryDirectory() as tmp:
         out_path = os.path.join(tmp, "rank0.json")
         launch.run(rank_fn, n, (argv, out_path))

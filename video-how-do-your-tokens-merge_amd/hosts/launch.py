@@ -52,7 +52,7 @@ def check_world(requested: int) -> Tuple[int, int, int]:
 
 def _rank_main(local_rank: int, worker: Callable, world: int, addr: str, port: int, args: Sequence) -> None:
     os.environ.update({"RANK": str(local_rank), "LOCAL_RANK": str(local_rank), "WORLD_SIZE": str(world),
-                       "MASTER_ADDR": addr, "MASTER_PORT": str(port)})
+                       "LOCAL_WORLD_SIZE": str(world), "MASTER_ADDR": addr, "MASTER_PORT": str(port)})
     worker(*args)
 
 
@@ -88,13 +88,20 @@ class _StdoutToStderr:
         return False
 
 
-def init_process_group(backend: str, device=None) -> None:
-    """Join the job's process group (no-op for a single process).  backend "nccl" is RCCL on ROCm."""
+def init_process_group(backend: str, device=None, force: bool = False) -> None:
+    """Join the job's process group (no-op for a single process).  backend "nccl" is RCCL on ROCm.
+    force (or TOME_FORCE_PROCESS_GROUP=1): a single process forms a group of one as well -- the way to run RCCL's
+    initialisation and the job's one collective on a box with a single GPU (tests/test_launch_gpu.py)."""
     import torch.distributed as dist
     _, _, world = rank_env()
-    if world == 1 or dist.is_initialized():
+    force = force or os.environ.get("TOME_FORCE_PROCESS_GROUP", "0") == "1"
+    if (world == 1 and not force) or dist.is_initialized():
         return
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if world == 1:
+        os.environ.setdefault("MASTER_PORT", str(free_port()))
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
     if backend == "nccl" and device is not None:
         dist.init_process_group(backend="nccl", device_id=device)
     else:

@@ -22,7 +22,6 @@ SYMBOLS = (
     "tome_drop",
     "tome_drop_regrouped",
     "tome_unmerge", "tome_row_map", "tome_source_init", "tome_gelu_erf",
-    "tome_profile_enable", "tome_profile_read",
 )
 
 ABI_VERSION = 6
@@ -42,11 +41,18 @@ def lib() -> ctypes.CDLL:
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    _lib = bind(LIB_PATH)
+    return _lib
+
+
+def bind(path: str) -> ctypes.CDLL:
+    """A library file with the C ABI of include/tome_hip.h, loaded and typed.  `lib()` binds the product library once;
+    bench.py's stage-timing leg binds the measurement build beside it (lib/libtome_hip_prof.so)."""
+    if not os.path.exists(path):
         raise TomeHipError(
-            f"HIP extension not found at {LIB_PATH}: the MI355X merge path has no fallback. "
+            f"HIP extension not found at {path}: the MI355X merge path has no fallback. "
             "Build it with `python video-how-do-your-tokens-merge_amd/csrc/build.py` (needs hipcc).")
-    L = ctypes.CDLL(LIB_PATH)
+    L = ctypes.CDLL(path)
     i64, i32, vp, sz = ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t
     L.tome_abi_version.restype = i32
     L.tome_abi_version.argtypes = []
@@ -104,13 +110,8 @@ def lib() -> ctypes.CDLL:
     L.tome_row_map.argtypes = [i64, i64, i64, i32, vp, vp, vp, vp, vp]
     L.tome_source_init.restype = i32
     L.tome_source_init.argtypes = [i64, i64, i64, i32, i32, vp, vp, vp]
-    L.tome_profile_enable.restype = i32
-    L.tome_profile_enable.argtypes = [i32]
-    L.tome_profile_read.restype = i32
-    L.tome_profile_read.argtypes = [vp, i32]
     if L.tome_abi_version() != ABI_VERSION:
-        raise TomeHipError(f"libtome_hip.so ABI {L.tome_abi_version()} != expected {ABI_VERSION}")
-    _lib = L
+        raise TomeHipError(f"{os.path.basename(path)} ABI {L.tome_abi_version()} != expected {ABI_VERSION}")
     return L
 
 
@@ -785,16 +786,3 @@ def source_init(plan: MatchPlan, drop: bool = False) -> torch.Tensor:
         _check(lib().tome_source_init(plan.n, plan.T, plan.r, int(plan.distill_token), int(bool(drop)),
                                       plan.row_map.data_ptr(), out.data_ptr(), st), "tome_source_init")
     return out
-
-
-def profile_enable(reps: int) -> None:
-    """reps > 0: time tome_match's stages, each kernel launched `reps` times back to back; 0: off."""
-    _check(lib().tome_profile_enable(int(reps)), "tome_profile_enable")
-
-
-def profile_read():
-    """Milliseconds of the stages {unit vectors, similarity + row max, rank + select} of the last
-    tome_match issued from this thread while profiling was on (waits for it to finish)."""
-    buf = (ctypes.c_float * 3)()
-    _check(lib().tome_profile_read(buf, 3), "tome_profile_read")
-    return [float(v) for v in buf]

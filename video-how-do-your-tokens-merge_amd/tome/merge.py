@@ -6,7 +6,6 @@ Reference lines each function stands in for (sjpollard/video-how-do-your-tokens-
   bipartite_soft_matching         tome/merge.py:17-102
   bipartite_soft_matching_drop    tome/merge.py:215-271
   bipartite_soft_matching_hybrid  tome/merge.py:274-352
-  kth_ / random_bipartite_soft_matching  tome/merge.py:105-212 (no patch uses them: torch ops on device)
   merge_wavg                      tome/merge.py:355-369
   merge_source                    tome/merge.py:372-384
   do_nothing                      tome/merge.py:13-14
@@ -169,77 +168,6 @@ def bipartite_soft_matching_hybrid(
     return merge, unmerge
 
 
-def _device_only(t: torch.Tensor, what: str) -> None:
-    _abi.require_device(t, what)
-
-
-def kth_bipartite_soft_matching(metric: torch.Tensor, k: int) -> Tuple[Callable, Callable]:
-    """Every k-th token is a destination, the k-1 before it are sources that ALL merge into their most
-    similar destination (tokens n -> n // k).  Reference: tome/merge.py:105-158.  No patch of the reference
-    calls this variant; it is kept for API completeness and runs as PyTorch-ROCm tensor ops on the tensors'
-    device (no hand-written kernel, and as everywhere in this package no CPU path)."""
-    if k <= 1:
-        return do_nothing, do_nothing
-    _device_only(metric, "kth_bipartite_soft_matching(metric)")
-
-    def split(x):
-        n, t, c = x.shape
-        groups = x[:, : (t // k) * k, :].view(n, -1, k, c)
-        return groups[:, :, : k - 1, :].reshape(n, -1, c), groups[:, :, k - 1, :]
-
-    with torch.no_grad():
-        unit = metric / metric.norm(dim=-1, keepdim=True)
-        a, b = split(unit)
-        r = a.shape[1]
-        dst_idx = (a @ b.transpose(-1, -2)).argmax(dim=-1)[..., None]
-
-    def merge(x: torch.Tensor, mode="mean") -> torch.Tensor:
-        src, dst = split(x)
-        n, _, c = src.shape
-        return dst.scatter_reduce(-2, dst_idx.expand(n, r, c), src, reduce=mode)
-
-    def unmerge(x: torch.Tensor) -> torch.Tensor:
-        n, _, c = x.shape
-        src = x.gather(dim=-2, index=dst_idx.expand(n, r, c)).to(x.dtype)
-        return torch.cat([src.view(n, -1, k - 1, c), x.view(n, -1, 1, c)], dim=-2).reshape(n, -1, c)
-
-    return merge, unmerge
-
-
-def random_bipartite_soft_matching(metric: torch.Tensor, r: int) -> Tuple[Callable, Callable]:
-    """r randomly chosen tokens are sources that merge into their most similar token among the rest (tokens
-    n -> n - r).  Reference: tome/merge.py:161-212; unused by the patches, PyTorch-ROCm tensor ops on device."""
-    if r <= 0:
-        return do_nothing, do_nothing
-    _device_only(metric, "random_bipartite_soft_matching(metric)")
-    with torch.no_grad():
-        B, N, _ = metric.shape
-        order = torch.rand(B, N, 1, device=metric.device).argsort(dim=1)
-        a_idx, b_idx = order[:, :r, :], order[:, r:, :]
-
-        def split(x):
-            c = x.shape[-1]
-            return x.gather(dim=1, index=a_idx.expand(B, r, c)), x.gather(dim=1, index=b_idx.expand(B, N - r, c))
-
-        unit = metric / metric.norm(dim=-1, keepdim=True)
-        a, b = split(unit)
-        dst_idx = (a @ b.transpose(-1, -2)).argmax(dim=-1)[..., None]
-
-    def merge(x: torch.Tensor, mode="mean") -> torch.Tensor:
-        src, dst = split(x)
-        c = src.shape[-1]
-        return dst.scatter_reduce(-2, dst_idx.expand(B, r, c), src, reduce=mode)
-
-    def unmerge(x: torch.Tensor) -> torch.Tensor:
-        c = x.shape[-1]
-        out = torch.zeros(B, N, c, device=x.device, dtype=x.dtype)
-        out.scatter_(dim=-2, index=a_idx.expand(B, r, c), src=x.gather(dim=-2, index=dst_idx.expand(B, r, c)))
-        out.scatter_(dim=-2, index=b_idx.expand(B, N - r, c), src=x)
-        return out
-
-    return merge, unmerge
-
-
 def merge_wavg(merge: Callable, x: torch.Tensor, size: Optional[torch.Tensor] = None, log_size: bool = False
                ) -> Tuple[torch.Tensor, torch.Tensor]:
     """Size-weighted average merge; returns the merged tensor and the new token sizes.  With a merge
@@ -262,9 +190,11 @@ def merge_source(merge: Callable, x: torch.Tensor, source: Optional[torch.Tensor
     """Source tracking: adjacency between the initial tokens and the merged groups."""
     plan = getattr(merge, "plan", None)
     if source is None:
-        if plan is not None:
+        if plan is not None and plan.edge_keep is None:
             # merging the identity with "max" = the one-hot rows of the matching's row map: written directly
-            # (tome_source_init), the [n, T, T] identity is never allocated
+            # (tome_source_init), the [n, T, T] identity is never allocated.  (Not for a hybrid matching: there a
+            # destination with an incoming edge below the threshold is zeroed before the amax, merge.py:326-331, so its
+            # own column is 0 -- the generic path below keeps that.)
             _abi.require_device(x, "merge_source(x)")
             if x.shape[0] != plan.n or x.shape[1] != plan.T or x.device != plan.device:
                 raise _abi.TomeHipError(f"merge_source: x {tuple(x.shape)} on {x.device} does not fit the matching "

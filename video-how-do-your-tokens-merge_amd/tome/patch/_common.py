@@ -101,12 +101,22 @@ def attention(q, k, v, size, scale: float, dropout_p: float = 0.0, bias_skip: bo
     return out.transpose(1, 2).reshape(B, N, H * hd)
 
 
+def _stock_module(m, cls) -> bool:
+    """`m` is exactly `cls` (not a subclass with a forward of its own: LoRA, quantised, ... layers), carries no
+    parametrization and no forward hook -- only then may its forward be replaced by a hand-made call."""
+    return (type(m) is cls and not getattr(m, "parametrizations", None)
+            and not m._forward_hooks and not m._forward_pre_hooks)
+
+
 def _plain_mlp(mlp) -> bool:
-    """An MLP of the usual shape: fc1, exact-erf nn.GELU, fc2, dropouts that are the identity in eval."""
+    """An MLP of the usual shape: fc1, exact-erf nn.GELU, fc2, dropouts that are the identity in eval -- all of them
+    the stock modules, unhooked (feature extractors / flop counters hook mlp, act, fc2: those run the module itself)."""
     act = getattr(mlp, "act", None)
     fc1, fc2 = getattr(mlp, "fc1", None), getattr(mlp, "fc2", None)
-    return (isinstance(act, torch.nn.GELU) and getattr(act, "approximate", "none") == "none"
-            and isinstance(fc1, torch.nn.Linear) and isinstance(fc2, torch.nn.Linear) and not mlp.training
+    return (act is not None and _stock_module(act, torch.nn.GELU) and getattr(act, "approximate", "none") == "none"
+            and fc1 is not None and _stock_module(fc1, torch.nn.Linear)
+            and fc2 is not None and _stock_module(fc2, torch.nn.Linear) and not mlp.training
+            and not mlp._forward_hooks and not mlp._forward_pre_hooks
             and set(dict(mlp.named_children())) <= {"fc1", "act", "fc2", "drop", "drop1", "drop2"})
 
 
@@ -131,7 +141,7 @@ def foldable(linear, eval_mode: bool = True):
     """`linear` when the block's last step `x = x + linear(h)` may run as ONE GEMM that accumulates onto the residual
     stream in place (`x.addmm_(h, Wᵀ)`, finish_linear) -- which needs the bias in the stream beforehand
     (merge_then_norm's `fold`, the merge kernel's x_out_bias); None when it may not."""
-    if (_FUSE_FC2 and _FUSE_NEXT and eval_mode and isinstance(linear, torch.nn.Linear) and linear.bias is not None
+    if (_FUSE_FC2 and _FUSE_NEXT and eval_mode and _stock_module(linear, torch.nn.Linear) and linear.bias is not None
             and not (torch.is_grad_enabled() and linear.weight.requires_grad)):
         return linear
     return None
