@@ -668,3 +668,51 @@ def test_reference_command_lines_run(tmp_path, capsys):
     assert out[("TOME.ENABLE", "True", "TOME.R_VALUE", "0")] == out[()]
     with pytest.raises(SystemExit):
         harness.main_run_net(["--cfg", str(y)])  # TRAIN.ENABLE True: training is out of scope, said loudly
+
+
+def test_second_forward_on_another_stream_is_ordered_not_concurrent(monkeypatch):
+    """Two forwards in flight on two HIP streams of one process deadlock on this platform (the library's persistent
+    Stream-K GEMM grids wait on each other: tools/probes/two_stream_gemm.py is the minimal reproduction, round 2's
+    tools/two_stream.py the original observation).  The patched forward therefore orders itself behind a patched
+    forward that is still in flight on another stream (`_common._guard_one_forward_in_flight`: the stream waits for
+    that forward's end event, one RuntimeWarning), or refuses with TOME_ONE_FORWARD=raise.  Made deterministic here by
+    a spin kernel in front of the first forward: its end event cannot be complete when the second forward is issued."""
+    import warnings
+    tome, H = _hosts()
+    from tome.patch import _common
+    torch.manual_seed(0)
+    models = []
+    for _ in range(2):
+        torch.manual_seed(0)
+        m = H["videomae"].VideoMAE(num_frames=8, img_size=64, patch_size=16, embed_dim=128, depth=3, num_heads=2,
+                                   num_classes=9).to(DEV).to(torch.bfloat16).eval()
+        tome.patch.videomae(m, prop_attn=False)
+        m.r = 4
+        models.append(m)
+    clip = torch.rand(4, 3, 8, 64, 64, device=DEV).to(torch.bfloat16)
+    with torch.no_grad():
+        want = models[0]([clip]).clone()
+        torch.cuda.synchronize()
+        s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+        monkeypatch.setattr(_common, "_warned_two_streams", False)
+        _common._in_flight.clear()
+        with torch.cuda.stream(s1):
+            torch.cuda._sleep(200_000_000)  # ~0.1 s: the first forward is certainly still in flight below
+            out_a = models[0]([clip])
+        with warnings.catch_warnings(record=True) as caught:
+            warnings.simplefilter("always")
+            with torch.cuda.stream(s2):
+                out_b = models[1]([clip])
+        assert any(issubclass(w.category, RuntimeWarning) and "in flight" in str(w.message) for w in caught)
+        torch.cuda.synchronize()
+        assert torch.equal(out_a, want) and torch.equal(out_b, want)
+        # the refusing form
+        monkeypatch.setenv("TOME_ONE_FORWARD", "raise")
+        _common._in_flight.clear()
+        with torch.cuda.stream(s1):
+            torch.cuda._sleep(200_000_000)
+            models[0]([clip])
+        with torch.cuda.stream(s2), pytest.raises(RuntimeError, match="in flight"):
+            models[1]([clip])
+        torch.cuda.synchronize()
+        _common._in_flight.clear()

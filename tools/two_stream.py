@@ -6,8 +6,13 @@ LayerNorm / GELU passes of one half under the MFMA-bound GEMMs and attention of 
 
 Result on this pool (round 2): two forwards in flight on two streams of one process never finish -- also with
 r=0 and every TOME_* kernel switched off (TOME_ATTN_KERNEL=0 TOME_FUSE_NEXT=0 TOME_GELU_KERNEL=0), i.e. with the
-framework's kernels alone; each replica alone on its side stream is fine.  The script gives up after 40 s instead of
-hanging.  Not pursued: the product stays on one stream per process.
+framework's kernels alone; each replica alone on its side stream is fine.  Round 3 found the cause: every GEMM of the
+model runs as hipBLASLt's persistent Stream-K kernel (`..._SK3_..._MT256x256x64`, one workgroup per CU spinning on its
+siblings' partial tiles), and two such grids resident at once deadlock -- tools/probes/two_stream_gemm.py reproduces it
+with two chains of plain torch.mm (88 ms on one stream; not finished after 20 s on two).  Since then a patched forward
+issued while another is in flight on a different stream is ORDERED behind it (tome/patch/_common.py,
+`_guard_one_forward_in_flight`): this script now finishes, and shows that two streams buy nothing.  The script still
+gives up after 40 s instead of hanging, with the host stack dumped at 30 s.
 
 Prints clips/s for one stream over the whole batch and for S streams over batch/S clips each (S replicas of the
 patched model sharing nothing but the device; `_tome_info` is per model, so one forward at a time per replica).
@@ -34,7 +39,7 @@ def main():
     ap.add_argument("--offset", type=int, default=0, help="start replica k's forward k*offset layers late (host order)")
     a = ap.parse_args()
     import faulthandler
-    faulthandler.dump_traceback_later(45, repeat=True)  # where the host is, should a step never come back
+    faulthandler.dump_traceback_later(30, repeat=True)  # where the host is, should a step never come back
     import tome
     from hosts.videomae import videomae_base
     dev = torch.device("cuda", 0)

@@ -60,6 +60,48 @@ def new_tome_info(trace_source, prop_attn, mode, head_aggregation, threshold, ve
     }
 
 
+# One forward in flight per process.  Two patched (or unpatched) forwards issued on two HIP streams of one process never
+# finish on this platform: every GEMM of these models runs as hipBLASLt's persistent Stream-K kernel
+# (`Custom_Cijk_..._SK3_..._MT256x256x64`: one workgroup per CU, workgroups spin on each other's partial tiles), and two
+# such grids resident at once deadlock -- reproduced with two chains of plain `torch.mm` on two streams and nothing
+# else (tools/probes/two_stream_gemm.py: 88 ms on one stream, not finished after 20 s on two, with either BLAS
+# preference).  The reference's own contract is one forward at a time per model (`_tome_info` is shared state,
+# SURVEY 8b "Threading").  A patched forward issued while another one is still in flight on a different stream is
+# therefore ORDERED behind it (the stream waits for the other forward's end event; said once in a warning) instead of
+# hanging the device: two streams then buy no overlap, and nothing deadlocks.  TOME_ONE_FORWARD=raise refuses instead.
+_in_flight = {}  # device index -> (stream id, event recorded behind the last patched forward)
+_warned_two_streams = False
+
+
+def _guard_one_forward_in_flight(device) -> None:
+    global _warned_two_streams
+    if device.type != "cuda" or torch.cuda.is_current_stream_capturing():
+        return  # (a captured forward is ordered by the graph it is replayed from)
+    cur = torch.cuda.current_stream(device)
+    last = _in_flight.get(device.index)
+    if last is None or last[0] == cur.cuda_stream or last[1].query():
+        return
+    msg = ("a forward issued on another HIP stream of this process is still in flight: the library GEMMs of two "
+           "concurrent forwards (hipBLASLt Stream-K, persistent grids) deadlock on this platform")
+    if os.environ.get("TOME_ONE_FORWARD", "order") == "raise":
+        raise RuntimeError(msg + ".  Run one forward at a time per process (one process per GPU).")
+    cur.wait_event(last[1])
+    if not _warned_two_streams:
+        _warned_two_streams = True
+        import warnings
+        warnings.warn(msg + "; this forward has been ordered behind it (no overlap between the two streams).",
+                      RuntimeWarning, stacklevel=3)
+
+
+def _note_forward_issued(device) -> None:
+    if device.type != "cuda" or torch.cuda.is_current_stream_capturing():
+        return
+    cur = torch.cuda.current_stream(device)
+    ev = torch.cuda.Event()
+    ev.record(cur)
+    _in_flight[device.index] = (cur.cuda_stream, ev)
+
+
 def wrap_model_forward(model_wrapper: torch.nn.Module, blocks_of: Callable) -> None:
     """make_tome_class (videomae.py:160-169): every forward re-reads ``self.r`` into a per-layer list and
     clears size/source."""
@@ -73,7 +115,13 @@ def wrap_model_forward(model_wrapper: torch.nn.Module, blocks_of: Callable) -> N
         self._tome_info["source"] = None
         self._tome_info.pop("_prenorm", None)
         self._tome_info.pop("_folded", None)
-        return super(sub, self).forward(*args, **kwdargs)
+        param = next(self.parameters(), None)
+        if param is not None:
+            _guard_one_forward_in_flight(param.device)
+        out = super(sub, self).forward(*args, **kwdargs)
+        if param is not None:
+            _note_forward_issued(param.device)
+        return out
 
     sub = type("ToMeVisionTransformer", (base,), {"forward": forward, "_tome_tag": "ToMeVisionTransformer"})
     model_wrapper.__class__ = sub
