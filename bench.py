@@ -218,7 +218,9 @@ def measure_kernels(batch: int, t0: int, r: int, dev, reps: int = 10, isolated: 
         for name, ms in zip(("k_unit_rows_heads", "k_scores_rowmax", "k_rank_select"), acc):
             stats[name]["ms"] += ms
             stats[name]["launches"] += 1
-        stats["k_unit_rows_heads"]["bytes"] += batch * t * HEAD_DIM * (2 * HEADS + 4)  # read 12 heads, write fp32 units
+        # read 12 heads; write the bf16 head mean in fragment order + norm + 1/norm (the candidate-filter path of the
+        # matching, csrc/tome_match_filter.h; round 2 wrote fp32 unit vectors: 4 bytes per channel instead of 2)
+        stats["k_unit_rows_heads"]["bytes"] += batch * t * (HEAD_DIM * (2 * HEADS + 2) + 8)
         stats["k_scores_rowmax"]["flops"] += batch * 2 * t1 * t2 * HEAD_DIM
         stats["k_scores_rowmax"]["bytes"] += batch * t * HEAD_DIM * 4
         stats["k_rank_select"]["bytes"] += batch * (t1 * 8 + t1 * 8)
@@ -699,6 +701,12 @@ def worker(args):
                     "GB/s": round(v["bytes"] / (v["ms"] / 1e3) / 1e9, 1) if v["ms"] > 0 else None,
                     "TFLOP/s": round(v["flops"] / (v["ms"] / 1e3) / 1e12, 2) if v["flops"] else None}
                 for k, v in stats.items()}
+            out["merge_path_kernels"]["k_scores_rowmax"]["stage"] = (
+                "similarity + row max of the matching, as one timed stage: k_scores_filter (approximate scores on the "
+                "bf16 matrix pipe, candidate columns per row) + k_exact_rows (the contract's fp32 chain for the "
+                "candidates) + k_units_from_means / k_scores_rowmax for tiles whose candidate lists overflowed (none on "
+                "this data); TFLOP/s = SURVEY 8d's 2*T1*T2*D per group / stage time, i.e. what an all-pairs fp32 pass "
+                "would have to sustain (peak of that pipe: 157.3)")
             out["merge_path_ms_per_step"] = round(sum(v["ms"] for v in stats.values()), 4)
             with torch.no_grad():
                 out["attention_kernel"] = measure_attention(B, t0_tokens, args.r, dev)

@@ -91,6 +91,116 @@ def test_match_bit_exact_vs_oracle(kind, shape):
         np.testing.assert_array_equal(got.row_map.cpu().numpy(), want_map)
 
 
+def _filter_metric(kind, n, T, D, seed):
+    """bf16 metrics that stress the candidate filter of csrc/tome_match_filter.h in different ways."""
+    g = np.random.default_rng(seed)
+    if kind == "normal":
+        m = synth.normal_like((n, T, D), seed)
+    elif kind == "clustered":          # few directions + small noise: many near-ties inside the window
+        m = synth.clustered((n, T, D), seed)
+    elif kind == "duplicates":         # exact ties: every token exists 8 times -> lists overflow -> fp32 pass
+        base = synth.normal_like((n, max(1, (T + 7) // 8), D), seed)
+        m = np.tile(base, (1, 8, 1))[:, :T]
+    elif kind == "ramp":               # odd tokens approach every even token's direction along j: each new column is
+        d = synth.normal_like((n, 1, D), seed)   # a new running maximum -> long record sequences -> overflow
+        noise = synth.normal_like((n, T, D), seed + 1)
+        w = np.linspace(3.0, 0.02, T, dtype=np.float32).reshape(1, T, 1)
+        m = d + w * noise
+    elif kind == "nan":                # zero / NaN / inf tokens among normal ones (merge.py:51 has no epsilon)
+        m = synth.normal_like((n, T, D), seed)
+        for gi in range(n):
+            idx = g.choice(T, size=min(5, T), replace=False)
+            m[gi, idx[0]] = 0.0
+            if len(idx) > 1:
+                m[gi, idx[1], 0] = np.nan
+            if len(idx) > 2:
+                m[gi, idx[2], 1] = np.inf
+    elif kind == "tiny":               # tokens whose squared norm underflows (norm 0, unit channels +-inf): the filter
+        m = synth.normal_like((n, T, D), seed)   # must stand aside
+        m[:, ::7] *= 1e-33
+    elif kind == "huge":               # tokens whose squared norm overflows (norm inf, unit vector 0): likewise
+        m = synth.normal_like((n, T, D), seed)
+        m[:, ::5] *= 1e25
+    elif kind == "scales":             # norms spread over 2^-40 .. 2^40: the reciprocal scaling is exercised
+        m = synth.normal_like((n, T, D), seed)
+        m *= np.exp2(g.integers(-40, 41, size=(n, T, 1))).astype(np.float32)
+    else:
+        raise ValueError(kind)
+    return torch.from_numpy(np.ascontiguousarray(m)).to(torch.bfloat16)
+
+
+def _same_plan(a, b, what):
+    for name in ("src_idx", "dst_idx", "unm_idx"):
+        assert torch.equal(getattr(a, name), getattr(b, name)), f"{what}: {name}"
+    assert torch.equal(a.node_max.view(torch.int32), b.node_max.view(torch.int32)), f"{what}: node_max bits"
+
+
+@pytest.mark.parametrize("kind", ["normal", "clustered", "duplicates", "ramp", "nan", "tiny", "huge", "scales"])
+@pytest.mark.parametrize("n,T,D", [(3, 197, 64), (2, 784, 64), (1, 1568, 64), (4, 65, 16), (2, 3, 8), (2, 64, 64),
+                                   (1, 3137, 64), (5, 130, 40)])
+def test_match_candidate_filter_is_bit_identical_to_the_fp32_pass(kind, n, T, D, monkeypatch):
+    """bf16 metrics through the candidate filter (approximate scores on the bf16 matrix pipe, exact fp32 chain for the
+    candidates of every row, fp32 pass for flagged tiles: csrc/tome_match_filter.h; TOME_SCORES_FILTER=2 forces it on
+    small launches too) against the same call with the filter off (k_scores_rowmax on every tile) and against the
+    oracle on the rounded values: src / dst / unm indices and the BITS of node_max, with and without a class token /
+    a protected column, for r in {5, 16, all}.  The kinds cover the filter's every exit: one candidate per row, near-ties
+    inside the window, exact ties and monotone columns (list overflow -> fp32 pass of that tile), NaN / zero / inf tokens,
+    norms outside the trusted range (whole matching on the fp32 pass), norms spread over 80 binades."""
+    from tome import _abi
+    metric = _filter_metric(kind, n, T, D, 1234 + 13 * T + D).to(DEV)
+    host = metric.float().cpu().numpy()
+    for r, cls, dist in ((5, False, False), (16, True, False), (T, False, True)):
+        monkeypatch.setenv("TOME_SCORES_FILTER", "0")
+        want = _abi.match(metric, r, cls, dist, want_node_max=True)
+        monkeypatch.setenv("TOME_SCORES_FILTER", "2")
+        got = _abi.match(metric, r, cls, dist, want_node_max=True)
+        if want is None:
+            assert got is None
+            continue
+        _same_plan(got, want, f"{kind} r={r} cls={cls} distill={dist}")
+        # (oracle comparison: not for NaN tokens -- that rule is pinned by test_nan_rule... -- and not for "tiny": a
+        # token whose squared norm underflows has +-inf unit channels, its scores are NaN without its unit vector
+        # being NaN, a case outside the NaN-flag contract of both paths alike)
+        if kind not in ("nan", "tiny"):
+            plan = oracle.match(host, r, cls, dist)
+            np.testing.assert_array_equal(got.src_idx.cpu().numpy(), plan.src_idx)
+            np.testing.assert_array_equal(got.dst_idx.cpu().numpy(), plan.dst_idx)
+            np.testing.assert_array_equal(got.unm_idx.cpu().numpy(), plan.unm_idx)
+            np.testing.assert_array_equal(got.node_max.cpu().numpy().view(np.uint32), plan.node_max.view(np.uint32))
+
+
+@pytest.mark.parametrize("kind", ["normal", "clustered", "duplicates", "nan"])
+@pytest.mark.parametrize("n,H,T", [(3, 12, 197), (2, 12, 1568), (4, 2, 66), (16, 12, 196)])
+def test_match_keys_candidate_filter_is_bit_identical(kind, n, H, T, monkeypatch):
+    """The production entry (tome_match_keys: head mean inside the kernel, keys read in place from a qkv buffer)
+    with the candidate filter forced on vs off: identical indices and node_max bits."""
+    from tome import _abi
+    qkv = torch.zeros(n, T, 3, H, 64, dtype=torch.bfloat16)
+    for h in range(H):
+        qkv[:, :, 1, h] = _filter_metric(kind, n, T, 64, 777 + 31 * h + T)
+    keys = qkv.to(DEV).permute(2, 0, 3, 1, 4)[1]
+    for r, cls in ((16, False), (7, True)):
+        monkeypatch.setenv("TOME_SCORES_FILTER", "0")
+        want = _abi.match_keys(keys, r, cls, False, want_node_max=True)
+        monkeypatch.setenv("TOME_SCORES_FILTER", "2")
+        got = _abi.match_keys(keys, r, cls, False, want_node_max=True)
+        _same_plan(got, want, f"{kind} r={r} cls={cls}")
+
+
+def test_match_candidate_filter_runs_by_itself_on_large_launches(monkeypatch):
+    """Without the switch the filter serves launches of >= 1024 A tiles (the benchmark's: 384 x 25): same answer as
+    the fp32 pass at that size."""
+    from tome import _abi
+    monkeypatch.delenv("TOME_SCORES_FILTER", raising=False)
+    g = torch.Generator(device=DEV).manual_seed(11)
+    qkv = torch.randn(48, 1568, 3, 12, 64, device=DEV, generator=g).bfloat16()
+    keys = qkv.permute(2, 0, 3, 1, 4)[1]
+    got = _abi.match_keys(keys, 16, want_node_max=True)
+    monkeypatch.setenv("TOME_SCORES_FILTER", "0")
+    want = _abi.match_keys(keys, 16, want_node_max=True)
+    _same_plan(got, want, "48 x 1568")
+
+
 def test_match_exact_ties_are_stable():
     """Duplicate tokens give exactly equal scores: first maximal column wins, equal node_max keep row
     order (the contract's tie rule; the reference's argsort leaves this undefined)."""

@@ -28,6 +28,7 @@
 #include "../../include/tome_hip.h"
 #include "tome_common.h"
 #include "tome_match.h"
+#include "tome_match_filter.h"
 #include "tome_merge.h"
 #include "tome_attn.h"
 #include "tome_attn_stream.h"
@@ -147,6 +148,13 @@ struct MatchWs {
     uint8_t *badA, *badB;
     int ntA, ntB, nchunk;
     int64_t groupA_f4, groupB_f4;  // float4 per group of each unit set
+    // the filter path (tome_match_filter.h; D <= 64): bf16 means in MFMA fragment order, norms, candidate lists
+    uint4 *vA, *vB;
+    float *normA, *normB, *invB, *node_max;
+    int *node_idx, *any_flag;
+    CandEntry *cand;
+    uint8_t *cand_n, *tile_flag;
+    int T2p;
     size_t bytes;
 };
 
@@ -167,6 +175,21 @@ static MatchWs carve(void *base, int64_t n, int64_t T, int64_t D) {
     w.rank = (int *)(b + off); off = align_up(off + sizeof(int) * (size_t)(n * T1), 256);
     w.badA = (uint8_t *)(b + off); off = align_up(off + (size_t)(n * T1), 256);
     w.badB = (uint8_t *)(b + off); off = align_up(off + (size_t)(n * (T2 > 0 ? T2 : 1)), 256);
+    w.T2p = w.ntB * TILE_ROWS;
+    w.vA = w.vB = nullptr;
+    if (w.nchunk == 1) {
+        w.vA = (uint4 *)(b + off); off = align_up(off + 4096 * (size_t)(n * w.ntA), 256);
+        w.vB = (uint4 *)(b + off); off = align_up(off + 4096 * (size_t)(n * (w.ntB > 0 ? w.ntB : 1)), 256);
+        w.normA = (float *)(b + off); off = align_up(off + sizeof(float) * (size_t)(n * T1), 256);
+        w.normB = (float *)(b + off); off = align_up(off + sizeof(float) * (size_t)(n * (T2 > 0 ? T2 : 1)), 256);
+        w.invB = (float *)(b + off); off = align_up(off + sizeof(float) * (size_t)(n * (w.T2p > 0 ? w.T2p : 1)) + 64, 256);
+        w.node_max = (float *)(b + off); off = align_up(off + sizeof(float) * (size_t)(n * T1), 256);
+        w.node_idx = (int *)(b + off); off = align_up(off + sizeof(int) * (size_t)(n * T1), 256);
+        w.cand = (CandEntry *)(b + off); off = align_up(off + sizeof(CandEntry) * 2 * FILT_KH * (size_t)(n * T1), 256);
+        w.cand_n = (uint8_t *)(b + off); off = align_up(off + 2 * (size_t)(n * T1), 256);
+        w.tile_flag = (uint8_t *)(b + off); off = align_up(off + (size_t)(n * w.ntA), 256);
+        w.any_flag = (int *)(b + off); off = align_up(off + 256, 256);
+    }
     w.bytes = off;
     return w;
 }
@@ -196,10 +219,21 @@ static int launch_select(const MatchWs &w, int nparts, bool nan_flags, int64_t n
     return TOME_OK;
 }
 
+// The filter path (tome_match_filter.h) serves bf16 metrics of at most 64 channels when the launch has enough A tiles
+// to fill the chip with one wave per tile; everything else keeps the fp32 pass.  TOME_SCORES_FILTER=0 switches it off
+// (measurement switch, read per call).
+static bool use_filter(const MatchWs &w, int dtype, int64_t n, int64_t D) {
+    const char *e = getenv("TOME_SCORES_FILTER");
+    if (e && e[0] == '0') return false;
+    const int64_t min_tiles = (e && e[0] == '2') ? 1 : 1024;  // ("2": also for small launches -- the tests)
+    return dtype == TOME_BF16 && w.nchunk == 1 && D % 8 == 0 && w.ntB > 0 && w.T2p <= FILT_MAX_T2P &&
+           n * w.ntA >= min_tiles;
+}
+
 // shared tail of tome_match / tome_match_keys: stages 2 (similarity + row max) and 3 (rank + select)
-static int match_tail(const MatchWs &w, int64_t n, int64_t T, int64_t re, int class_token, int distill_token,
+static int match_tail(const MatchWs &w, int64_t n, int64_t T, int64_t D, int64_t re, int class_token, int distill_token,
                       int64_t *src_idx, int64_t *dst_idx, int64_t *unm_idx, float *node_max, int32_t *row_map,
-                      hipStream_t st) {
+                      hipStream_t st, bool filtered) {
     const int T1 = (int)((T + 1) / 2), T2 = (int)(T / 2);
     const int prof_reps = prof_reps_now();
     // 2. similarity + row max/argmax: one single-wave workgroup per (group, A tile, j-part); the B tiles are
@@ -214,22 +248,49 @@ static int match_tail(const MatchWs &w, int64_t n, int64_t T, int64_t re, int cl
     if (WJ > w.ntB) WJ = w.ntB;
     if (WJ < 1) WJ = 1;
     const unsigned nb2 = (unsigned)(((n + 7) / 8) * 8 * w.ntA * WJ);
-    for (int rep = 0; rep < prof_reps; ++rep)
-    if (w.nchunk == 1)
-        hipLaunchKernelGGL(k_scores_rowmax<true>, dim3(nb2), dim3(64), 0, st, (const f32x4 *)w.unitA,
-                           (const f32x4 *)w.unitB, (int)n, T1, T2, w.nchunk, w.ntA, w.ntB, WJ, w.groupA_f4,
-                           w.groupB_f4, distill_token, w.part_max, w.part_idx);
-    else
-        hipLaunchKernelGGL(k_scores_rowmax<false>, dim3(nb2), dim3(64), 0, st, (const f32x4 *)w.unitA,
-                           (const f32x4 *)w.unitB, (int)n, T1, T2, w.nchunk, w.ntA, w.ntB, WJ, w.groupA_f4,
-                           w.groupB_f4, distill_token, w.part_max, w.part_idx);
-    if (int rc = check_launch("k_scores_rowmax")) return rc;
+    for (int rep = 0; rep < prof_reps; ++rep) {
+        if (filtered) {
+            // 2a. approximate scores on the bf16 matrix pipe, candidate columns per row (tome_match_filter.h)
+            hipLaunchKernelGGL(k_scores_filter, dim3((unsigned)(((n + 7) / 8) * 8 * ((w.ntA + FILT_ATW - 1) / FILT_ATW))),
+                               dim3(64), sizeof(float) * (size_t)w.T2p, st, w.vA, w.vB,
+                               w.normA, w.invB, (int)n, T1, T2, w.T2p, w.ntA, w.ntB, distill_token, w.cand, w.cand_n,
+                               w.tile_flag, w.any_flag);
+            if (int rc = check_launch("k_scores_filter")) return rc;
+            // 2b. tiles whose candidate lists overflowed take the fp32 pass: unit vectors, then k_scores_rowmax on
+            // the flagged tiles only (both return at once when nothing is flagged)
+            hipLaunchKernelGGL(k_units_from_means, dim3(1024), dim3(256), 0, st, w.vA, w.vB, w.normA, w.normB, (int)n,
+                               (int)T, w.ntA, w.ntB, w.unitA, w.unitB, w.groupA_f4, w.groupB_f4, w.any_flag);
+            if (int rc = check_launch("k_units_from_means")) return rc;
+        }
+        const uint8_t *tflag = filtered ? w.tile_flag : nullptr;
+        if (w.nchunk == 1)
+            hipLaunchKernelGGL(k_scores_rowmax<true>, dim3(nb2), dim3(64), 0, st, (const f32x4 *)w.unitA,
+                               (const f32x4 *)w.unitB, (int)n, T1, T2, w.nchunk, w.ntA, w.ntB, WJ, w.groupA_f4,
+                               w.groupB_f4, distill_token, w.part_max, w.part_idx, tflag);
+        else
+            hipLaunchKernelGGL(k_scores_rowmax<false>, dim3(nb2), dim3(64), 0, st, (const f32x4 *)w.unitA,
+                               (const f32x4 *)w.unitB, (int)n, T1, T2, w.nchunk, w.ntA, w.ntB, WJ, w.groupA_f4,
+                               w.groupB_f4, distill_token, w.part_max, w.part_idx, tflag);
+        if (int rc = check_launch("k_scores_rowmax")) return rc;
+        if (filtered) {
+            // 2c. the exact score of every row's winner
+            hipLaunchKernelGGL(k_exact_rows, dim3((unsigned)((n * T1 + 255) / 256)), dim3(256), 0, st, w.vA, w.vB,
+                               w.normA, w.normB, (int)n, T1, T2, (int)D, w.ntA, w.ntB, w.cand, w.cand_n, w.tile_flag,
+                               w.part_max, w.part_idx, WJ, distill_token, w.node_max, w.node_idx);
+            if (int rc = check_launch("k_exact_rows")) return rc;
+        }
+    }
     prof_mark(2, st);
 
     // 3. rank + select
     int rc = TOME_OK;
+    MatchWs ws = w;
+    if (filtered) {
+        ws.part_max = w.node_max;
+        ws.part_idx = w.node_idx;
+    }
     for (int rep = 0; rep < prof_reps && rc == TOME_OK; ++rep)
-        rc = launch_select(w, WJ, true, n, T, re, class_token, distill_token, src_idx, dst_idx, unm_idx, node_max, row_map, st);
+        rc = launch_select(ws, filtered ? 1 : WJ, true, n, T, re, class_token, distill_token, src_idx, dst_idx, unm_idx, node_max, row_map, st);
     prof_mark(3, st);
     prof_done(rc);
     return rc;
@@ -256,10 +317,18 @@ extern "C" int tome_match(const void *metric, int dtype, int64_t n, int64_t T, i
     const size_t es = dtype == TOME_F32 ? 4 : 2;
     const bool fast = (D % 8 == 0) && (((uintptr_t)metric) % 16 == 0) && ((stride_n * es) % 16 == 0) &&
                       ((stride_t * es) % 16 == 0);
+    const bool filtered = fast && use_filter(w, dtype, n, D);
     bool launched = false;
     const int prof_reps = prof_reps_now();
     for (int rep = 0; rep < prof_reps; ++rep) {
     launched = false;
+    if (filtered) {
+        (void)hipMemsetAsync(w.any_flag, 0, sizeof(int), st);
+        hipLaunchKernelGGL(k_unit_rows_f<false>, dim3((unsigned)((n * T + 31) / 32)), dim3(256), 0, st,
+                           (const bf16_t *)metric, stride_n, 1, (int64_t)0, (int64_t)0, stride_t, (int)n, 1, (int)T, (int)D,
+                           w.vA, w.vB, w.ntA, w.ntB, w.normA, w.normB, w.invB, w.T2p, w.badA, w.badB, w.any_flag);
+        continue;
+    }
 #define UNIT_FAST(TY, NCH)                                                                                    \
     hipLaunchKernelGGL((k_unit_rows<TY, NCH>), dim3((unsigned)((n * T + 31) / 32)), dim3(256), 0, st,          \
                        (const TY *)metric, stride_n, stride_t, (int)n, (int)T, (int)D, w.unitA, w.unitB,       \
@@ -303,7 +372,7 @@ extern "C" int tome_match(const void *metric, int dtype, int64_t n, int64_t T, i
     if (int rc = check_launch("k_unit_rows")) return rc;
     prof_mark(1, st);
 
-    return match_tail(w, n, T, re, class_token, distill_token, src_idx, dst_idx, unm_idx, node_max, row_map, st);
+    return match_tail(w, n, T, D, re, class_token, distill_token, src_idx, dst_idx, unm_idx, node_max, row_map, st, filtered);
 }
 
 extern "C" int tome_match_keys(const void *keys, int dtype, int64_t n, int64_t H, int64_t T, int64_t D,
@@ -335,7 +404,15 @@ extern "C" int tome_match_keys(const void *keys, int dtype, int64_t n, int64_t H
     prof_mark(0, st);
     const int prof_reps = prof_reps_now();
     const unsigned nb = (unsigned)((n * T + 31) / 32);
+    const bool filtered = use_filter(w, dtype, n, D);
     for (int rep = 0; rep < prof_reps; ++rep) {
+        if (filtered) {
+            (void)hipMemsetAsync(w.any_flag, 0, sizeof(int), st);
+            hipLaunchKernelGGL(k_unit_rows_f<true>, dim3(nb), dim3(256), 0, st, (const bf16_t *)keys, stride_n, (int)inner,
+                               stride_inner, stride_h, stride_t, (int)n, (int)H, (int)T, (int)D, w.vA, w.vB, w.ntA, w.ntB,
+                               w.normA, w.normB, w.invB, w.T2p, w.badA, w.badB, w.any_flag);
+            continue;
+        }
         switch (dtype) {
         case TOME_F32:
             hipLaunchKernelGGL(k_unit_rows_heads<float>, dim3(nb), dim3(256), 0, st, (const float *)keys, stride_n,
@@ -356,7 +433,7 @@ extern "C" int tome_match_keys(const void *keys, int dtype, int64_t n, int64_t H
     }
     if (int rc = check_launch("k_unit_rows_heads")) return rc;
     prof_mark(1, st);
-    return match_tail(w, n, T, re, class_token, distill_token, src_idx, dst_idx, unm_idx, node_max, row_map, st);
+    return match_tail(w, n, T, D, re, class_token, distill_token, src_idx, dst_idx, unm_idx, node_max, row_map, st, filtered);
 }
 
 extern "C" int tome_match_scores(const float *scores, int64_t n, int64_t T, int64_t r, int class_token,

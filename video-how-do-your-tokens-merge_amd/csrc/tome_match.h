@@ -293,7 +293,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SCORES_WAVES
                                                       const f32x4 *__restrict__ unitB, int n, int T1, int T2,
                                                       int nchunk, int ntA, int ntB, int WJ, int64_t groupA_f4,
                                                       int64_t groupB_f4, int distill_token,
-                                                      float *__restrict__ part_max, int *__restrict__ part_idx) {
+                                                      float *__restrict__ part_max, int *__restrict__ part_idx,
+                                                      const uint8_t *__restrict__ tile_flag) {
     // XCD-aware block -> (group, tile, part) map: blocks b and b+8 share an XCD (round-robin dispatch),
     // so all work items of one group -- which stream the same B tiles -- get ids congruent mod 8 and
     // find those tiles in their XCD's L2.  Placement only affects speed.
@@ -304,6 +305,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SCORES_WAVES
     if (g >= n) return;
     const int item = qq % per_group;
     const int ti = item / WJ, part = item % WJ;
+    // behind the candidate filter (tome_match_filter.h) only the tiles it flagged are computed here
+    if (tile_flag && !tile_flag[(int64_t)g * ntA + ti]) return;
 
     const int lane = threadIdx.x;
     const int col = lane & 31, h = lane >> 5;
