@@ -39,7 +39,7 @@ enum tome_status {
     TOME_ELAUNCH = 3     /* HIP reported a launch error (text in tome_last_error()) */
 };
 
-#define TOME_ABI_VERSION 6
+#define TOME_ABI_VERSION 7
 
 int tome_abi_version(void);
 

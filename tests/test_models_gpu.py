@@ -716,3 +716,82 @@ def test_second_forward_on_another_stream_is_ordered_not_concurrent(monkeypatch)
             models[1]([clip])
         torch.cuda.synchronize()
         _common._in_flight.clear()
+
+
+@pytest.mark.parametrize("host_name", ["videomae", "vivit", "timesformer", "motionformer"])
+def test_block_output_with_and_without_the_fc2_fold_bf16(host_name, monkeypatch):
+    """The fc2 fold changes the rounding order of a block's last residual against the reference: the reference rounds
+    x' + round(h W + b), the fold rounds round(x' + b) + h W accumulated in the GEMM (bias put into the stream by the
+    merge kernel's x_out_bias, `finish_linear` with beta = 1).  A doubled or missing bias in ONE block would be hidden
+    by a model-level logit tolerance, so this holds single blocks to each other: every block's OUTPUT with the fold on
+    vs off (same input to the block, captured by hooks in the unfolded run and replayed) within 2 bf16 ulps of the
+    largest magnitude of that output row... and the fold must actually have been taken and consumed (`_folded`)."""
+    tome, H = _hosts()
+    from tome.patch import _common
+    torch.manual_seed(0)
+    if host_name == "videomae":
+        model = H["videomae"].VideoMAE(num_frames=8, img_size=64, patch_size=16, embed_dim=128, depth=3, num_heads=2,
+                                       num_classes=9)
+        patch, frames = tome.patch.videomae, 8
+    elif host_name == "vivit":
+        model = H["vivit"].ViViT(num_classes=9, image_size=64, num_frames=8, hidden_size=128, num_hidden_layers=3,
+                                 num_attention_heads=2, intermediate_size=256)
+        patch, frames = tome.patch.vivit, 8
+    elif host_name == "timesformer":
+        model = H["timesformer"].TimeSformer(num_frames=4, img_size=64, patch_size=8, embed_dim=128, depth=3,
+                                             num_heads=2, num_classes=9)
+        patch, frames = tome.patch.timesformer, 4
+    else:
+        model = H["motionformer"].Motionformer(img_size=64, patch_size=8, patch_size_temp=2, temporal_resolution=4,
+                                               embed_dim=128, depth=3, num_heads=2, num_classes=9)
+        patch, frames = tome.patch.motionformer, 8
+    model = model.to(DEV).to(torch.bfloat16).eval()
+    # give every bias a size that would show if it were applied twice or not at all
+    with torch.no_grad():
+        for name, p_ in model.named_parameters():
+            if name.endswith("bias"):
+                p_.copy_(torch.randn_like(p_) * 0.5)
+    patch(model)
+    clip = torch.rand(3, 3, frames, 64, 64, device=DEV).to(torch.bfloat16)
+    blocks = [m for m in model.modules() if getattr(m.__class__, "_tome_tag", None) in ("ToMeBlock", "ToMeVivitLayer")]
+    assert len(blocks) == 3
+    outs = {}
+    for fold in (False, True):
+        monkeypatch.setattr(_common, "_FUSE_FC2", fold)
+        seen = []
+        hooks = [b.register_forward_hook(lambda m, i, o, seen=seen: seen.append((o[0] if isinstance(o, tuple) else o).float().clone()))
+                 for b in blocks]
+        folded_taken = []
+        real_fl = _common.finish_linear
+
+        def spy_fl(block, x, h, linear, info):
+            folded_taken.append(info.get("_folded") is not None)
+            return real_fl(block, x, h, linear, info)
+        monkeypatch.setattr(_common, "finish_linear", spy_fl)
+        logits, plans = _trace(tome, model, clip, 4)
+        logits = logits.float()
+        for hk in hooks:
+            hk.remove()
+        monkeypatch.setattr(_common, "finish_linear", real_fl)
+        outs[fold] = (seen, logits, folded_taken, model._tome_info.get("_folded"), [p for _, p in plans])
+    (s0, l0, f0, left0, p0), (s1, l1, f1, left1, p1) = outs[False], outs[True]
+    assert not any(f0) and left0 is None
+    if host_name in ("videomae", "vivit"):
+        assert f1 and all(f1), "the fold was not taken in every block"
+    print(f"{host_name}: finish_linear calls with a folded bias: {sum(f1)} of {len(f1)}")
+    assert left1 is None, "a folded bias was left unconsumed at the end of the forward"
+    assert len(s0) == len(s1) == 3
+    compared = 0
+    for k, (a, b) in enumerate(zip(s0, s1)):
+        assert a.shape == b.shape
+        # block 0 sees identical input in both runs; a later block is comparable as long as every matching up to and
+        # including its own chose the same tokens (an ulp of difference upstream may legitimately merge others)
+        same = all(torch.equal(getattr(x, n_), getattr(y, n_)) for x, y in zip(p0[:k + 1], p1[:k + 1])
+                   for n_ in ("src_idx", "dst_idx", "unm_idx"))
+        if k > 0 and not same:
+            break
+        tol = 2.0 * 2 ** -8 * float(a.abs().max()) * (k + 1)
+        assert float((a - b).abs().max()) <= tol, (k, float((a - b).abs().max()), tol)
+        compared += 1
+    print(f"{host_name}: {compared} block outputs compared")
+    assert compared >= 1

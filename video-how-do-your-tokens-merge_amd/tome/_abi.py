@@ -24,7 +24,7 @@ SYMBOLS = (
     "tome_unmerge", "tome_row_map", "tome_source_init", "tome_gelu_erf",
 )
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 DTYPES = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}
 MODES = {"sum": 0, "mean": 1, "amax": 2, "max": 2, "prod": 3, "amin": 4, "min": 4}
 
