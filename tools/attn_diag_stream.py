@@ -35,8 +35,10 @@ st = buf.reshape(WGS, 8, NS).astype(np.int64)[:256]
 t = st[:, :, :6] * 0.01
 names = ["tile loop", "loop done->last product, stores issued", "->next tile staged, behind the barrier",
          "->Q fragment ready", "->first tile's weights"]
+ntile = (N + 63) // 64
 for w in (0, 7):
-    print(f"wave {w}:")
+    print(f"wave {w}:   (per step: wait for the tile requested one step earlier {np.median(st[:, w, 6]) * 0.01 / (ntile - 1):.3f} us, "
+          f"request + barrier {np.median(st[:, w, 7]) * 0.01 / (ntile - 1):.3f} us; instrumented steps are slower)")
     for i, nm in enumerate(names):
         d = t[:, w, i + 1] - t[:, w, i]
         print(f"   {nm:38s} median {np.median(d):7.2f} us  mean {d.mean():7.2f}")

@@ -192,6 +192,10 @@ __global__ __launch_bounds__(512, 2) void k_prop_attention_stream(AttnArgs a, in
 
     att_f32x16 o0, o1, negm, s0, s1;
     float m_run = -INFINITY, l_run = 0.0f;
+#ifdef ATT_DIAG
+    int diag_n = 0;
+    unsigned long long diag_wait_stage = 0, diag_wait_barrier = 0;
+#endif
     auto item_reset = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int v = 0; v < 16; ++v) o0[v] = o1[v] = negm[v] = 0.0f;
@@ -342,9 +346,27 @@ __global__ __launch_bounds__(512, 2) void k_prop_attention_stream(AttnArgs a, in
     // one pipelined step inside an item: tile tn (in the staging registers) -> slot S, the stream's next tile
     // requested, ONE barrier, S(tn) and O += V(tn-1) P(tn-1), then P(tn) against the item's reference point
     auto fast_step = [&](int S, int tn, bool masked) __attribute__((always_inline)) {
+#ifdef ATT_DIAG
+        // (diagnostic build: how long does a step wait for the tile it requested one step ago, and at the barrier?)
+        unsigned long long d0_ = 0, d1_ = 0, d2_ = 0;
+        if (diag_n == 2) d0_ = __builtin_amdgcn_s_memrealtime();
+#endif
         stage_write(S);
+#ifdef ATT_DIAG
+        if (diag_n == 2) {
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            d1_ = __builtin_amdgcn_s_memrealtime();
+        }
+#endif
         stream_load();
         __syncthreads();
+#ifdef ATT_DIAG
+        if (diag_n == 2) {
+            d2_ = __builtin_amdgcn_s_memrealtime();
+            diag_wait_stage += d1_ - d0_;
+            diag_wait_barrier += d2_ - d1_;
+        }
+#endif
         scores(S, negm, masked && last_half);
         pv(false);
         v_fragments(S);
@@ -457,9 +479,6 @@ __global__ __launch_bounds__(512, 2) void k_prop_attention_stream(AttnArgs a, in
     if (!item_ok(item)) return;  // (then so is every later item of this workgroup)
     cold_start(item);
     int par = 0;  // ring slot of the current item's tile 0
-#ifdef ATT_DIAG
-    int diag_n = 0;
-#endif
     for (;;) {
         ATS_STAMP(0);  // tile loop starts
         // ---- steps inside the item: tiles 1 .. ntiles-1 (tile tn -> slot (par + tn) & 1)
@@ -471,6 +490,12 @@ __global__ __launch_bounds__(512, 2) void k_prop_attention_stream(AttnArgs a, in
             for (int tn = 1; tn < ntiles; ++tn) helper_step((par + tn) & 1);
         }
         ATS_STAMP(1);  // tile loop done
+#ifdef ATT_DIAG
+        if (diag_n == 2 && blockIdx.x < ATT_DIAG_WGS && lane == 0) {
+            g_att_stamps[((size_t)blockIdx.x * 8 + wave) * ATT_DIAG_N + 6] = diag_wait_stage;
+            g_att_stamps[((size_t)blockIdx.x * 8 + wave) * ATT_DIAG_N + 7] = diag_wait_barrier;
+        }
+#endif
         // ---- switch: the staging registers hold the next item's tile 0 (if there is a next item).  Order: everything
         // that READS memory for the next item is issued first (its tile 0 to LDS, its Q rows, its tile 1), then the
         // current item's last product, normalisation and stores -- a wait for any of those loads then never waits

@@ -516,7 +516,19 @@ static int launch_merge_rows(const void *x, const void *size, int64_t n, int64_t
                 !aligned16(ln_p->bias))
                 return fail(TOME_EINVAL, "fused LayerNorm needs 16-bit tokens with C <= 1024 and 16-byte aligned buffers");
             if constexpr (OP == OP_WAVG && sizeof(TX) == 2) {
-                if (nit == 3)
+                // many destinations receive sources: the streaming waves skip those rows (EAGER, csrc/tome_merge.h);
+                // TOME_MERGE_EAGER=0 / 1 forces it off / on where r <= 64 (measurement switch, read per call)
+                const char *ee = getenv("TOME_MERGE_EAGER");
+                const bool eager = r <= 64 && ((ee && ee[0] == '1') || (!(ee && ee[0] == '0') && 8 * r >= T));
+                if (eager && nit == 3)
+                    hipLaunchKernelGGL((k_merge_rows_fast<TX, TS, OP, 3, true, true>), grid, dim3(256), 0, st, (const TX *)x,
+                                       (const TS *)size, (int)n, (int)T, (int)C, (int)r, R, (int)cpr, (int)((To + R - 1) / R), src, dst, unm,
+                                       distill, keep, (TX *)xout, (TS *)sout, lin, lout, cls_rows, *ln_p, (TS *)lsout);
+                else if (eager)
+                    hipLaunchKernelGGL((k_merge_rows_fast<TX, TS, OP, 6, true, true>), grid, dim3(256), 0, st, (const TX *)x,
+                                       (const TS *)size, (int)n, (int)T, (int)C, (int)r, R, (int)cpr, (int)((To + R - 1) / R), src, dst, unm,
+                                       distill, keep, (TX *)xout, (TS *)sout, lin, lout, cls_rows, *ln_p, (TS *)lsout);
+                else if (nit == 3)
                     hipLaunchKernelGGL((k_merge_rows_fast<TX, TS, OP, 3, true>), grid, dim3(256), 0, st, (const TX *)x,
                                        (const TS *)size, (int)n, (int)T, (int)C, (int)r, R, (int)cpr, (int)((To + R - 1) / R), src, dst, unm,
                                        distill, keep, (TX *)xout, (TS *)sout, lin, lout, cls_rows, *ln_p, (TS *)lsout);

@@ -624,7 +624,12 @@ __global__ __launch_bounds__(256) void k_merge_rows(const TX *__restrict__ x, co
 #define FAST_NIT 6
 #define FAST_MAXR 4
 
-template <typename TX, typename TS, int OP, int NIT, bool LN = false>
+// EAGER (round 3): when r is a large share of the destinations (TimeSformer / Motionformer late layers, r = 32 sweeps:
+// r >= T2 / 4) the streaming waves first wait for dst_idx and do NOT read the rows that receive sources -- those are
+// read (own row + sources) by the edge waves anyway; without it they were read twice (measured, tools/regroup_layers.py:
+// 5.4 TB/s at 196 -> 164 tokens per group falling to 3.2 at 68 -> 36).  Costs the streaming waves of such launches one
+// dependent round trip (index -> rows), which the default path avoids for the r << T2 case of the benchmark.
+template <typename TX, typename TS, int OP, int NIT, bool LN = false, bool EAGER = false>
 __global__ __launch_bounds__(256) void k_merge_rows_fast(const TX *__restrict__ x, const TS *__restrict__ size,
                                                          int n, int T_, int C, int r, int R, int cpr,
                                                          int rg_per_group, const int64_t *__restrict__ src_idx,
@@ -789,7 +794,13 @@ __global__ __launch_bounds__(256) void k_merge_rows_fast(const TX *__restrict__ 
     // rows that exist; which of them receive sources (and are left to the edge waves) is decided AFTER the row loads
     // have been issued -- a row that turns out to be one is read for nothing (r of T rows), but no row load waits for
     // dst_idx
-    const bool va0 = vmask & 1ull, va1 = vmask & 2ull, va2 = vmask & 4ull, va3 = vmask & 8ull;
+    bool va0 = vmask & 1ull, va1 = vmask & 2ull, va2 = vmask & 4ull, va3 = vmask & 8ull;
+    if (EAGER && OP != OP_DROP) {  // (r <= 64: the host's condition -- every dst_idx entry of the group is in d_first)
+        va0 = va0 && (__ballot(d_first == j0) == 0ull);
+        va1 = va1 && (__ballot(d_first == j1) == 0ull);
+        va2 = va2 && (__ballot(d_first == j2) == 0ull);
+        va3 = va3 && (__ballot(d_first == j3) == 0ull);
+    }
 
     // flattened chunk loop: chunk q of the R-row slab -> (row q / cpr, 16-byte column q % cpr)
     const int total = R * cpr;
