@@ -2,7 +2,10 @@
 """Phase timeline of k_prop_attention's query blocks from the DIAGNOSTIC build (-DATT_DIAG: s_memrealtime stamps; never
 the shipped library):   bash tools/ab_lib.sh diag "-DATT_DIAG";  TOME_HIP_LIB=.../lib/ab_diag.so python tools/attn_diag.py [B H N]
 Prints, per phase, the median / mean time over the recorded workgroups (wave 0), the skew between the first and the
-last wave of a workgroup, and the idle gap on a CU between one workgroup's last store and the next one's entry."""
+last wave of a workgroup, and how many CU slots were busy on average (sum of workgroup durations / recorded span:
+256 = no gap between consecutive workgroups of a CU).
+    TOME_ATTN_STREAM=0 python tools/attn_diag.py ...   # k_prop_attention (one workgroup per query block)
+    python tools/attn_diag_stream.py ...                # k_prop_attention_stream (persistent workgroups)"""
 import collections
 import ctypes
 import os
@@ -53,29 +56,5 @@ end = t[:, :, 6]
 print(f"  entry skew over the 8 waves of a workgroup  median {np.median(ent.max(1) - ent.min(1)):6.2f} us;"
       f" end skew {np.median((end.max(1) - end.min(1))[full]):6.2f} us")
 wg_start, wg_end = ent.min(1), end.max(1)
-hw = st[:, 0, 7]
-cu = (hw >> 8) & 0xF | ((hw >> 13) & 0x7) << 4 | ((hw >> 12) & 1) << 7  # cu, se, sh
-xcc = st[:, 0, 7] >> 16  # not the XCC id on every ASIC; placement is also told apart by time overlap below
-per = collections.defaultdict(list)
-for i in range(nwg):
-    per[int(hw[i] & 0xFFF0 | 0)].append((wg_start[i], wg_end[i]))
-gaps = []
-for key, lst in per.items():
-    lst.sort()
-    # several XCDs share one (se, sh, cu) code: split into chains of non-overlapping workgroups greedily
-    chains = []
-    for s, e in lst:
-        for c in chains:
-            if s >= c[-1][1] - 0.05:
-                c.append((s, e))
-                break
-        else:
-            chains.append([(s, e)])
-    for c in chains:
-        gaps += [c[j + 1][0] - c[j][1] for j in range(len(c) - 1)]
-gaps = np.array(gaps)
-if gaps.size:
-    print(f"  idle gap between consecutive workgroups of one CU slot: median {np.median(gaps):6.2f} us  mean {gaps.mean():6.2f}"
-          f"  (n = {gaps.size})")
 span = wg_end.max() - wg_start.min()
 print(f"  recorded span {span:8.1f} us; sum of workgroup durations / span = {float((wg_end - wg_start).sum() / span):6.1f} (CU slots busy)")
