@@ -9,6 +9,8 @@ the drop-in `tome` package (ctypes -> C ABI -> gfx950 kernels), against
 
 Nothing here reads /root/reference.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -199,6 +201,19 @@ def test_match_candidate_filter_runs_by_itself_on_large_launches(monkeypatch):
     monkeypatch.setenv("TOME_SCORES_FILTER", "0")
     want = _abi.match_keys(keys, 16, want_node_max=True)
     _same_plan(got, want, "48 x 1568")
+
+
+def test_match_candidate_filter_random_campaign():
+    """tools/filter_fuzz.py: 150 random shapes / key statistics (scales over 40 binades, low-rank keys with cosines
+    packed within 1e-4, duplicated tokens, a nearly constant token) / r / class token / protected column, filter on vs
+    off: indices and node_max bits identical.  (600 cases of two other seeds ran clean when the path was built.)"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "tools", "filter_fuzz.py"), "150", "20261005"], capture_output=True,
+                       text=True, timeout=600)
+    assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-2000:])
+    assert "150 cases, 0 mismatches" in p.stdout
 
 
 def test_match_exact_ties_are_stable():

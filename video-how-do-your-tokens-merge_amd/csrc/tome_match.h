@@ -288,8 +288,10 @@ __device__ unsigned long long g_diag_stamps[TOME_DIAG_SLOTS * 2];
                         // profiles/r02_scores_occupancy.txt): 8 float4 / 4 waves (106 VGPRs) 99.0 TF/s; 4 float4 / 5 waves
                         // (94 VGPRs) 100.4; 4 float4 / 6 waves (80 VGPRs, 60 B of scratch) 77.3 -- occupancy is not the lever
 #endif
+// (the multi-chunk form -- D > 64: the "concat" metric -- reloads its A fragments per chunk and spilled 12 bytes per
+// lane at five waves per SIMD; it is given the registers of four)
 template <bool ONE_CHUNK>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SCORES_WAVES, 8))) void k_scores_rowmax(const f32x4 *__restrict__ unitA,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ONE_CHUNK ? SCORES_WAVES : 4, 8))) void k_scores_rowmax(const f32x4 *__restrict__ unitA,
                                                       const f32x4 *__restrict__ unitB, int n, int T1, int T2,
                                                       int nchunk, int ntA, int ntB, int WJ, int64_t groupA_f4,
                                                       int64_t groupB_f4, int distill_token,
