@@ -359,7 +359,9 @@ __global__ __launch_bounds__(512, 2) void k_prop_attention_stream(AttnArgs a, in
         }
 #endif
         stream_load();
-        __syncthreads();
+#if !defined(ATS_ABL) || !(ATS_ABL & 1)
+        __syncthreads();  // (ATS_ABL & 1: measurement build without it -- results wrong by design)
+#endif
 #ifdef ATT_DIAG
         if (diag_n == 2) {
             d2_ = __builtin_amdgcn_s_memrealtime();
