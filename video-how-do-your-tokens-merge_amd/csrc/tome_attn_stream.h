@@ -38,13 +38,19 @@
 #define ATS_STAMP(i)
 #endif
 
+#define ATS_BIAS_GROUP 4  // tiles per bias load (power of two; 2 * GROUP * 64 words of LDS)
+#ifdef ATS_ABL
+#define ATS_ABL_BIT(b) ((ATS_ABL & (b)) != 0)
+#else
+#define ATS_ABL_BIT(b) false
+#endif
 template <typename TX, bool BIAS>
 __global__ __launch_bounds__(512, 2) void k_prop_attention_stream(AttnArgs a, int nitems) {
     constexpr int WAVES = 8;
     constexpr int ATT_BM = 32 * WAVES;
     __shared__ __attribute__((aligned(16))) short lds_k[ATT_SLOTS][ATT_BN * ATT_KS];
     __shared__ __attribute__((aligned(16))) short lds_v[ATT_SLOTS][ATT_BN * ATT_VS];
-    __shared__ __attribute__((aligned(16))) float lds_bias[ATT_SLOTS][ATT_BN];
+    __shared__ __attribute__((aligned(16))) unsigned lds_bias[2][ATS_BIAS_GROUP * ATT_BN];  // BIAS: (hi | lo << 16) per key, see bias_step()
     __shared__ __attribute__((aligned(16))) short lds_o[WAVES][32 * ATT_KS];  // a wave's output block on its way out
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -99,7 +105,8 @@ __global__ __launch_bounds__(512, 2) void k_prop_attention_stream(AttnArgs a, in
     const unsigned koff = (unsigned)(((int64_t)r0 * a.k_sn + 8 * c0) * 2), koff_p = (unsigned)(((int64_t)rp * a.k_sn + 8 * c0) * 2);
     const unsigned voff = (unsigned)(((int64_t)r0 * a.v_sn + 8 * c0) * 2), voff_p = (unsigned)(((int64_t)rp * a.v_sn + 8 * c0) * 2);
     uint4 kreg, vreg;
-    float breg = 0.0f;
+    unsigned breg = 0u;
+    int r_sub = 0, b_par = 0, b_off = 0;  // BIAS: the staged tile's place in its group, the group buffer in use
     // The stream: the next tile to request is tile s_t of item s_item and starts at s_kt / s_vt (bias row: s_ls).
     // n_q / n_o / n_qb: where that item's query block and output block start -- once the stream has moved on to the
     // item after the one being computed (two steps before the switch) these describe the computing side's NEXT item.
@@ -127,9 +134,19 @@ __global__ __launch_bounds__(512, 2) void k_prop_attention_stream(AttnArgs a, in
         const bool part = s_t >= nfull;  // wave-uniform
         kreg = *reinterpret_cast<const uint4 *>(s_kt + (part ? koff_p : koff));
         vreg = *reinterpret_cast<const uint4 *>(s_vt + (part ? voff_p : voff));
-        if (BIAS && tid < ATT_BN) {
+        // BIAS: the per-key term of ATS_BIAS_GROUP tiles at a time, one key per thread -- staging it tile by tile
+        // put ~25 instructions per step on wave 0 alone, and every wave waits for the slowest at the barrier
+        // (measured: 10 % of the kernel)
+        r_sub = s_t & (ATS_BIAS_GROUP - 1);
+        if (BIAS && r_sub == 0 && tid < ATS_BIAS_GROUP * ATT_BN && !ATS_ABL_BIT(2)) {
             const int key = min(s_t * ATT_BN + tid, nk - 1);
-            breg = key >= bias_skip ? s_ls[key - bias_skip] * LOG2E : 0.0f;
+            // log2-domain bias as two 16-bit terms hi + lo (what is left is below 2^-15 of the bias for bf16)
+            const float bv = key >= bias_skip ? s_ls[key - bias_skip] * LOG2E : 0.0f;
+            const short bh = att_bits<TX>(bv);
+            TX th;
+            __builtin_memcpy(&th, &bh, 2);
+            const short bl = att_bits<TX>(bv - to_f32(th));
+            breg = (unsigned)(unsigned short)bh | ((unsigned)(unsigned short)bl << 16);
         }
         if (++s_t == ntiles) {
             if (item_ok(s_item + G)) stream_set(s_item + G);
@@ -143,7 +160,13 @@ __global__ __launch_bounds__(512, 2) void k_prop_attention_stream(AttnArgs a, in
     auto stage_write = [&](int S) __attribute__((always_inline)) {
         *reinterpret_cast<uint4 *>(wk + S * ATT_BN * ATT_KS) = kreg;
         *reinterpret_cast<uint4 *>(wv + S * ATT_BN * ATT_VS) = vreg;
-        if (BIAS && tid < ATT_BN) lds_bias[0][S * ATT_BN + tid] = breg;
+        if (BIAS) {  // (wave-uniform) a tile that opens a group brings the group's bias words along
+            if (r_sub == 0) {
+                b_par ^= 1;
+                if (tid < ATS_BIAS_GROUP * ATT_BN) lds_bias[b_par][tid] = breg;
+            }
+            b_off = b_par * (ATS_BIAS_GROUP * ATT_BN) + r_sub * ATT_BN;  // where the tile now in slot S finds its words
+        }
     };
 
     // ---- per-item state of the computing side
@@ -221,23 +244,26 @@ __global__ __launch_bounds__(512, 2) void k_prop_attention_stream(AttnArgs a, in
                 vfr[kb][p][3] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(va + 8 * ATT_VS + 32));
             }
     };
-    auto add_bias = [&](int S, att_f32x16 &c0v, att_f32x16 &c1v) __attribute__((always_inline)) {
-        const float *brow = &lds_bias[0][0] + S * ATT_BN + 4 * hf;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const float4 b0 = *reinterpret_cast<const float4 *>(brow + 8 * g);
-            const float4 b1 = *reinterpret_cast<const float4 *>(brow + 32 + 8 * g);
-            c0v[4 * g + 0] = __builtin_fmaf(bfac, b0.x, c0v[4 * g + 0]); c0v[4 * g + 1] = __builtin_fmaf(bfac, b0.y, c0v[4 * g + 1]);
-            c0v[4 * g + 2] = __builtin_fmaf(bfac, b0.z, c0v[4 * g + 2]); c0v[4 * g + 3] = __builtin_fmaf(bfac, b0.w, c0v[4 * g + 3]);
-            c1v[4 * g + 0] = __builtin_fmaf(bfac, b1.x, c1v[4 * g + 0]); c1v[4 * g + 1] = __builtin_fmaf(bfac, b1.y, c1v[4 * g + 1]);
-            c1v[4 * g + 2] = __builtin_fmaf(bfac, b1.z, c1v[4 * g + 2]); c1v[4 * g + 3] = __builtin_fmaf(bfac, b1.w, c1v[4 * g + 3]);
-        }
+    // BIAS: the per-key term rides on the matrix pipe as a fifth k-step of the score product -- K gets two more
+    // "channels" (hi, lo of the bias), Q gets bfac in both -- instead of 32 fma + 8 wide LDS reads per tile on the
+    // vector pipe; the lanes of the upper half (channels 8..15 of that k-step) hold zeros
+    auto bias_step = [&](int S) __attribute__((always_inline)) {
+        const unsigned w0 = lds_bias[0][b_off + col], w1 = lds_bias[0][b_off + 32 + col];
+        const unsigned one = (unsigned)(unsigned short)att_bits<TX>(bfac);
+        const unsigned qw = hf ? 0u : (one | (one << 16));
+        const uint4 q5 = make_uint4(qw, 0u, 0u, 0u), k0 = make_uint4(hf ? 0u : w0, 0u, 0u, 0u), k1 = make_uint4(hf ? 0u : w1, 0u, 0u, 0u);
+        att_s16x8 fq, f0, f1;
+        __builtin_memcpy(&fq, &q5, 16);
+        __builtin_memcpy(&f0, &k0, 16);
+        __builtin_memcpy(&f1, &k1, 16);
+        s0 = AttMfma<TX>::run(f0, fq, s0);
+        s1 = AttMfma<TX>::run(f1, fq, s1);
     };
     auto scores = [&](int S, const att_f32x16 &cinit, bool first_half_only) __attribute__((always_inline)) {
         const short *ks0 = kbase + S * ATT_BN * ATT_KS;
         s0 = cinit;
         s1 = cinit;
-        if (BIAS) add_bias(S, s0, s1);
+        if (BIAS && !ATS_ABL_BIT(4)) bias_step(S);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks)
             s0 = AttMfma<TX>::run(*reinterpret_cast<const att_s16x8 *>(ks0 + 16 * ks), qf[ks], s0);
