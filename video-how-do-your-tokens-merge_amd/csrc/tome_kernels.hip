@@ -919,7 +919,13 @@ static int prop_attention_impl(const void *q, const void *k, const void *v, int 
     const char *se = getenv("TOME_ATTN_STREAM");
     const int64_t sn_max = 1 << 22;  // (the stream kernel keeps token offsets inside a tile / query block in 32 bits)
     const bool sn_ok = a.q_sn < sn_max && a.k_sn < sn_max && a.v_sn < sn_max && a.o_sn < sn_max;
-    if (waves == 8 && Nk > ATT_BN && sn_ok && !(se && se[0] == '0')) {
+    // (Round 3: also for launches the rule above gives four waves, as long as a block has work for more than four --
+    // 8 x 12 x 1568: 597 -> 650 TFLOP/s, with the per-key bias 476 -> 537; 64 x 12 x 197: 242 -> 280 / 199 -> 240;
+    // level at 16 x 12 x 197 and below, where the launch is the cost; the 4-wave persistent form was built and
+    // measured too: 17-20 % slower than this one at 197 .. 1568 tokens, not kept)
+    const bool stream_ok = Nk > ATT_BN && sn_ok && !(se && se[0] == '0');
+    if (stream_ok && (waves == 8 || (!waves_env && N > 128))) {
+        const int64_t qblocks = (N + 255) / 256;
         static const int cus = [] {
             int dev = 0, n = 0;
             if (hipGetDevice(&dev) != hipSuccess ||
