@@ -39,7 +39,7 @@ enum tome_status {
     TOME_ELAUNCH = 3     /* HIP reported a launch error (text in tome_last_error()) */
 };
 
-#define TOME_ABI_VERSION 7
+#define TOME_ABI_VERSION 8
 
 int tome_abi_version(void);
 
@@ -220,12 +220,15 @@ int tome_prop_attention_segments(const void *q, const void *k, const void *v, in
  * tome_trajectory_mix  <-  the temporal stage of ToMeTrajectoryAttention.forward (tome/patch/motionformer.py:122-139):
  *     attn = softmax(einsum('b h s d, b h s f d -> b h s f', q2 * scale, k2)); x = einsum('b h s f, b h s f d -> b h s d', attn, v2)
  * q2 [B, S, H*64]; k2, val [B, S, F, H*64] views whose (b, s, f) rows are k_row_stride / v_row_stride elements apart
- * (k2 = first half of the proj_kv output, val = the trajectory tokens or its second half); out [B, S, H*64];
- * tattn NULL or fp32 [B, H, S, F].  16-bit tensors, head dim 64, H <= 16, F <= 8; fp32 arithmetic inside.
+ * (k2 = first half of the proj_kv output, val = the trajectory tokens or its second half); out [B, S, H*64] rows,
+ * batch b starting out_batch_stride elements after batch b-1 (0 = S*H*64, contiguous; larger: `out` is a slice of
+ * the [B, 1+S, C] buffer that also takes the class token's row, so that `torch.cat((cls_out, x), dim=1)` of
+ * motionformer.py:138 needs no copy); tattn NULL or fp32 [B, H, S, F].  16-bit tensors, head dim 64, H <= 16,
+ * F <= 8; fp32 arithmetic inside.
  */
 int tome_trajectory_mix(const void *q2, const void *k2, const void *val, int dtype, int64_t B, int64_t S, int64_t F,
                         int64_t H, int64_t D, int64_t k_row_stride, int64_t v_row_stride, float scale, void *out,
-                        float *tattn, tome_stream_t stream);
+                        int64_t out_batch_stride, float *tattn, tome_stream_t stream);
 
 /*
  * tome_add_layernorm  <-  the second residual of the patched block and the LayerNorm that consumes it:

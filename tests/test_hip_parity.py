@@ -1199,7 +1199,15 @@ def test_trajectory_mix_against_fp32_reference(B, S, F, H, dtype, tol):
         assert out.shape == (B, S, C) and out.dtype == dtype and attn.shape == (B, H, S, F)
         assert float((attn - want_attn).abs().max()) <= 1e-4
         assert float((out.float() - want).abs().max()) <= tol
+        # written straight behind a class row of a [B, 1+S, C] buffer (the patched Motionformer attention: no cat),
+        # without the attention map: the same bits, the neighbouring row untouched
+        joined = torch.full((B, 1 + S, C), 7.0, device=DEV, dtype=dtype)
+        out2, none = _abi.trajectory_mix(q2, k2, val, H, scale, want_attn=False, out=joined[:, 1:])
+        assert none is None and out2.data_ptr() == joined[:, 1:].data_ptr()
+        assert torch.equal(joined[:, 1:], out) and bool((joined[:, 0] == 7.0).all())
     assert not _abi.trajectory_mix_ok(q2.float(), kv[..., :C].float(), y.float(), H)
+    with pytest.raises(_abi.TomeHipError):
+        _abi.trajectory_mix(q2, kv[..., :C], y, H, scale, out=torch.empty(B, S, C + 8, device=DEV, dtype=dtype)[..., :C])
 
 
 @pytest.mark.parametrize("growth", [0.05, 1.0, 40.0])

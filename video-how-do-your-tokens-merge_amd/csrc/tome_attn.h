@@ -574,7 +574,7 @@ template <typename TX>
 __global__ __launch_bounds__(256) void k_trajectory_mix(const TX *__restrict__ q2, const TX *__restrict__ k2,
                                                         const TX *__restrict__ val, int64_t rows, int S, int F, int H,
                                                         int64_t k_row, int64_t v_row, float scale,
-                                                        TX *__restrict__ out, float *__restrict__ tattn) {
+                                                        TX *__restrict__ out, int64_t out_sb, float *__restrict__ tattn) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (row >= rows) return;  // wave-uniform
@@ -582,6 +582,9 @@ __global__ __launch_bounds__(256) void k_trajectory_mix(const TX *__restrict__ q
     const TX *qr = q2 + row * C;
     const TX *kr = k2 + row * F * k_row;
     const TX *vr = val + row * F * v_row;
+    // (out rows: batch b starts out_sb elements after batch b-1 -- the caller may hand a slice of a larger buffer)
+    const int64_t ob = row / S;
+    TX *const orow = out + ob * out_sb + (row - ob * S) * C;
     float acc[2][8];
     float w[2][TRAJ_MAXF];
 #pragma unroll
@@ -636,8 +639,7 @@ __global__ __launch_bounds__(256) void k_trajectory_mix(const TX *__restrict__ q
         for (int f = 0; f < TRAJ_MAXF; ++f) w[i][f] *= inv;
         if (tattn && on && (c & 7) == 0) {
             const int h = c >> 3;
-            const int64_t b = row / S, s = row - b * S;
-            float *tp = tattn + ((b * H + h) * S + s) * F;
+            float *tp = tattn + ((ob * H + h) * S + (row - ob * S)) * F;
             for (int f = 0; f < F; ++f) tp[f] = w[i][f];
         }
 #pragma unroll
@@ -651,6 +653,6 @@ __global__ __launch_bounds__(256) void k_trajectory_mix(const TX *__restrict__ q
                 for (int e = 0; e < 8; ++e) acc[i][e] = __builtin_fmaf(w[i][f], to_f32(pk.e[e]), acc[i][e]);
             }
         }
-        if (on) store_pack<TX, 8>(out + row * C + 8 * c, acc[i]);
+        if (on) store_pack<TX, 8>(orow + 8 * c, acc[i]);
     }
 }

@@ -968,7 +968,8 @@ extern "C" int tome_attn_diag_read(unsigned long long *host, int64_t count) {
 
 extern "C" int tome_trajectory_mix(const void *q2, const void *k2, const void *val, int dtype, int64_t B, int64_t S,
                                    int64_t F, int64_t H, int64_t D, int64_t k_row_stride, int64_t v_row_stride,
-                                   float scale, void *out, float *tattn, tome_stream_t stream) {
+                                   float scale, void *out, int64_t out_batch_stride, float *tattn,
+                                   tome_stream_t stream) {
     if (!q2 || !k2 || !val || !out || B <= 0 || S <= 0 || F <= 0 || H <= 0)
         return fail(TOME_EINVAL, "tome_trajectory_mix: bad shape/pointer");
     if (D != 64 || H > 16 || F > TRAJ_MAXF)
@@ -977,6 +978,9 @@ extern "C" int tome_trajectory_mix(const void *q2, const void *k2, const void *v
     if (k_row_stride % 8 || v_row_stride % 8 || k_row_stride < H * D || v_row_stride < H * D || !aligned16(q2) ||
         !aligned16(k2) || !aligned16(val) || !aligned16(out))
         return fail(TOME_EINVAL, "tome_trajectory_mix: rows must be 16-byte aligned");
+    if (out_batch_stride == 0) out_batch_stride = S * H * D;
+    if (out_batch_stride < S * H * D || out_batch_stride % 8)
+        return fail(TOME_EINVAL, "tome_trajectory_mix: out_batch_stride must be 0 or a multiple of 8 >= S*H*D");
     const int64_t rows = B * S;
     if (rows > 0x7fffffffLL) return fail(TOME_EINVAL, "tome_trajectory_mix: too many tokens");
     const dim3 grid((unsigned)((rows + 3) / 4));
@@ -984,11 +988,11 @@ extern "C" int tome_trajectory_mix(const void *q2, const void *k2, const void *v
     if (dtype == TOME_BF16)
         hipLaunchKernelGGL(k_trajectory_mix<bf16_t>, grid, dim3(256), 0, st, (const bf16_t *)q2, (const bf16_t *)k2,
                            (const bf16_t *)val, rows, (int)S, (int)F, (int)H, k_row_stride, v_row_stride, scale,
-                           (bf16_t *)out, tattn);
+                           (bf16_t *)out, out_batch_stride, tattn);
     else
         hipLaunchKernelGGL(k_trajectory_mix<f16_t>, grid, dim3(256), 0, st, (const f16_t *)q2, (const f16_t *)k2,
                            (const f16_t *)val, rows, (int)S, (int)F, (int)H, k_row_stride, v_row_stride, scale,
-                           (f16_t *)out, tattn);
+                           (f16_t *)out, out_batch_stride, tattn);
     return check_launch("k_trajectory_mix");
 }
 

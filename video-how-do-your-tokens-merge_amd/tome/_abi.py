@@ -24,7 +24,7 @@ SYMBOLS = (
     "tome_unmerge", "tome_row_map", "tome_source_init", "tome_gelu_erf",
 )
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 DTYPES = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}
 MODES = {"sum": 0, "mean": 1, "amax": 2, "max": 2, "prod": 3, "amin": 4, "min": 4}
 
@@ -97,7 +97,7 @@ def bind(path: str) -> ctypes.CDLL:
     L.tome_prop_attention_segments.argtypes = [vp, vp, vp, i32, i64, i64, i64, i64, i64, vp, vp, vp, vp, i64,
                                                ctypes.c_float, vp, vp, i64, vp, vp]
     L.tome_trajectory_mix.restype = i32
-    L.tome_trajectory_mix.argtypes = [vp, vp, vp, i32, i64, i64, i64, i64, i64, i64, i64, ctypes.c_float, vp, vp, vp]
+    L.tome_trajectory_mix.argtypes = [vp, vp, vp, i32, i64, i64, i64, i64, i64, i64, i64, ctypes.c_float, vp, i64, vp, vp]
     L.tome_drop_regrouped.restype = i32
     L.tome_drop_regrouped.argtypes = [vp, i32, i64, i64, i64, i64, i64, i32, vp, vp, vp]
     L.tome_drop.restype = i32
@@ -700,20 +700,26 @@ def trajectory_mix_ok(q2: torch.Tensor, k2: torch.Tensor, val: torch.Tensor, hea
 
 
 def trajectory_mix(q2: torch.Tensor, k2: torch.Tensor, val: torch.Tensor, heads: int, scale: float,
-                   want_attn: bool = True):
+                   want_attn: bool = True, out: Optional[torch.Tensor] = None):
     """softmax over the F frames of (q2*scale . k2[f]) per (batch, token, head), then the weighted sum of val[f]:
-    returns (out [B, S, C], attn [B, heads, S, F] fp32 or None)."""
+    returns (out [B, S, C], attn [B, heads, S, F] fp32 or None).  `out`: a [B, S, C] view with contiguous rows
+    (stride(1) == C) to write into -- e.g. rows 1.. of the [B, 1+S, C] buffer whose row 0 takes the class token."""
     if not trajectory_mix_ok(q2, k2, val, heads):
         raise TomeHipError("trajectory_mix: unsupported tensors (16-bit, head dim 64, <= 16 heads, <= 8 frames, "
                            "evenly spaced 16-byte aligned rows)")
     B, S, C = q2.shape
     F = k2.shape[2]
-    out = torch.empty((B, S, C), dtype=q2.dtype, device=q2.device)
+    if out is None:
+        out = torch.empty((B, S, C), dtype=q2.dtype, device=q2.device)
+    elif (tuple(out.shape) != (B, S, C) or out.dtype != q2.dtype or out.device != q2.device or out.stride(2) != 1
+          or out.stride(1) != C or out.stride(0) % 8 or out.stride(0) < S * C or out.data_ptr() % 16):
+        raise TomeHipError(f"trajectory_mix: out must be a {(B, S, C)} view of the q2 dtype with contiguous 16-byte "
+                           f"aligned rows, got {tuple(out.shape)} {out.dtype} strides {out.stride()}")
     attn = torch.empty((B, heads, S, F), dtype=torch.float32, device=q2.device) if want_attn else None
     with _on_device(q2.device):
         rc = lib().tome_trajectory_mix(q2.data_ptr(), k2.data_ptr(), val.data_ptr(), dtype_code(q2, "q2"), B, S, F, heads,
-                                       64, k2.stride(2), val.stride(2), float(scale), out.data_ptr(), _ptr(attn),
-                                       _stream(q2.device))
+                                       64, k2.stride(2), val.stride(2), float(scale), out.data_ptr(), out.stride(0),
+                                       _ptr(attn), _stream(q2.device))
     _check(rc, "tome_trajectory_mix")
     return out, attn
 

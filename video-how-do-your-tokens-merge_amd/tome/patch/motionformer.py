@@ -17,7 +17,7 @@ def _block_forward(self, x, seq_len=196, num_frames=8, approx="none", num_landma
     info = self._tome_info
     attn_size = info["size"] if info["prop_attn"] else None
     attn_out, _, metric = self.attn(C.first_norm(self, x, info, self.norm1), seq_len=seq_len, num_frames=num_frames,
-                                    approx=approx, num_landmarks=num_landmarks, size=attn_size)
+                                    approx=approx, num_landmarks=num_landmarks, size=attn_size, _want_attn=False)
     # x = x + attn; merge per group; norm2 -- one kernel when the layer merges 16-bit tokens
     x, y = C.merge_then_norm_regrouped(
         metric, x, info, self.norm2, lambda z: self.reduction_function(metric, z, info, num_frames),
@@ -32,10 +32,11 @@ def qkv_attn(q, k, v):
 
 
 def _trajectory_forward(self, x, seq_len=196, num_frames=8, approx="none", num_landmarks=128,
-                        size: torch.Tensor = None):
+                        size: torch.Tensor = None, _want_attn: bool = True):
     """ToMeTrajectoryAttention.forward (motionformer.py:33-144), exact attention only.  P is recomputed
     from the current token count; the size bias is added in the reference's '(s f)' order; the class
-    token's own attention ignores size; metric = head-mean of the keys regrouped '(s f) -> (b f) s'."""
+    token's own attention ignores size; metric = head-mean of the keys regrouped '(s f) -> (b f) s'.
+    _want_attn=False (the patched block, which drops the temporal attention map): the map is not written."""
     if approx != "none":
         raise NotImplementedError("ToMe Motionformer patch: only approx='none' (the reference's ToMe configs)")
     B, N, _ = x.shape
@@ -54,7 +55,10 @@ def _trajectory_forward(self, x, seq_len=196, num_frames=8, approx="none", num_l
     if fused:
         # the class token attends to every token, sizes ignored (motionformer.py:54): the attention kernel with one
         # query per head, read in place
-        cls_out = _abi.prop_attention(heads[0][:, :, :1], heads[1], heads[2], None, self.scale)
+        # (its row is row 0 of the buffer the temporal stage fills below: cat((cls_out, x), dim=1) without the copy)
+        joined = torch.empty((B, N, h * hd), dtype=qkv.dtype, device=qkv.device)
+        cls_out = _abi.prop_attention(heads[0][:, :, :1], heads[1], heads[2], None, self.scale,
+                                      out=joined[:, :1].unflatten(2, (h, hd)))
         # every token attends to the P keys of ONE frame at a time (softmax per frame): ONE launch of the segmented
         # attention kernel, queries and keys read in place from the qkv buffer, segment f writing its slice of
         # y 'b s f (h d)'; the [B*h, N, N] logits, their softmax and the attn @ v product never exist
@@ -84,8 +88,11 @@ def _trajectory_forward(self, x, seq_len=196, num_frames=8, approx="none", num_l
     if fused and _abi.trajectory_mix_ok(q2p, kv[..., :Cc], val_tok, h):
         # F logits per (token, head), their softmax and the weighted sum of the F trajectory tokens: one streaming
         # pass over k2 and val (tome_trajectory_mix) instead of two multiplies, two reductions and a softmax
-        out, tattn = _abi.trajectory_mix(q2p, kv[..., :Cc], val_tok, h, self.scale)
-        tattn = tattn.to(x.dtype)
+        out, tattn = _abi.trajectory_mix(q2p, kv[..., :Cc], val_tok, h, self.scale, want_attn=_want_attn,
+                                         out=joined[:, 1:])
+        if tattn is not None:
+            tattn = tattn.to(x.dtype)
+        out = joined  # class row + trajectory rows, already side by side
     else:
         q2 = rearrange(q2p, "b s (h d) -> b h s d", h=h) * self.scale
         k2 = rearrange(kv[..., :Cc], "b s f (h d) -> b h s f d", f=F, h=h)
@@ -94,7 +101,8 @@ def _trajectory_forward(self, x, seq_len=196, num_frames=8, approx="none", num_l
         tattn = (k2 * q2.unsqueeze(-2)).sum(dim=-1).softmax(dim=-1)
         val = rearrange(val_tok, "b s f (h d) -> b h s f d", f=F, h=h)
         out = rearrange((val * tattn.unsqueeze(-1)).sum(dim=-2), "b h s d -> b s (h d)")  # same remark
-    out = self.proj_drop(self.proj(torch.cat((cls_out, out), dim=1)))
+        out = torch.cat((cls_out.reshape(B, 1, -1), out), dim=1)
+    out = self.proj_drop(self.proj(out))
     # metric = rearrange(k_, '(b h) (s f) d -> (b f) h s d').mean(1) (motionformer.py:143-144): the regrouped keys
     # are a strided view of the qkv buffer -- [b, f, h, s, d] with token 1 + s*F + f -- and the head mean is taken
     # inside the matching kernel (tome_match_keys with inner groups), never as a tensor
