@@ -419,7 +419,7 @@ def also_workloads(dev, quick: bool = False):
     reference's own harness protocol (slowfast/utils/model_benchmark.py:20-58: batch 8, fresh torch.rand clip per
     iteration, one event pair per forward, 5 warm-up + 100 timed) eager and replayed from a HIP graph."""
     from hosts import harness
-    steps, warm = (3, 2) if quick else (8, 4)
+    steps, warm = (3, 2) if quick else (12, 6)  # (warm-up also covers the clock ramp after the idle model build)
     plan = [  # (key, family, r values, clips per step)
         ("videomae_b_8x224", "videomae_b_8x224", (16,), 128),
         ("timesformer_divst_8x224", "timesformer_divst_8x224", (8, 16, 32), 64),
