@@ -231,6 +231,18 @@ int tome_trajectory_mix(const void *q2, const void *k2, const void *val, int dty
                         int64_t out_batch_stride, float *tattn, tome_stream_t stream);
 
 /*
+ * tome_short_attention  <-  `self.temporal_attn(...)` in ToMeBlock.forward of the TimeSformer patch
+ * (tome/patch/timesformer.py:25-27): the host model's attention over the T <= 8 copies of one spatial token,
+ *     softmax(q k^T * scale) v        per (sequence, head), sequences = 'b (p t) m -> (b p) t m'
+ * q, k, v: [B, H, N, 64] views ({batch, head, token} element strides; the heads of a token side by side: head
+ * stride 64 -- the slices of a qkv projection read in place); out [B, N, H*64] contiguous.  16-bit tensors,
+ * N <= 8, fp32 arithmetic inside.  No bias term: the temporal attention never sees token sizes.
+ */
+int tome_short_attention(const void *q, const void *k, const void *v, int dtype, int64_t B, int64_t H, int64_t N,
+                         int64_t D, const int64_t *q_strides, const int64_t *k_strides, const int64_t *v_strides,
+                         float scale, void *out, tome_stream_t stream);
+
+/*
  * tome_add_layernorm  <-  the second residual of the patched block and the LayerNorm that consumes it:
  *     x = x + self.drop_path(self.mlp(self.norm2(x)))      (tome/patch/videomae.py:29)
  *     ... next ToMeBlock.forward: self.norm1(x)            (tome/patch/videomae.py:19)

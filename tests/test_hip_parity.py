@@ -1210,6 +1210,44 @@ def test_trajectory_mix_against_fp32_reference(B, S, F, H, dtype, tol):
         _abi.trajectory_mix(q2, kv[..., :C], y, H, scale, out=torch.empty(B, S, C + 8, device=DEV, dtype=dtype)[..., :C])
 
 
+@pytest.mark.parametrize("dtype,tol", [(torch.bfloat16, 2.0 ** -8), (torch.float16, 2.0 ** -11)])
+@pytest.mark.parametrize("B,H,N", [(37, 12, 8), (3, 2, 5), (1, 1, 1), (700, 16, 8), (4097, 12, 8), (9, 5, 3)])
+def test_short_attention_against_fp32_reference(B, H, N, dtype, tol):
+    """tome_short_attention (TimeSformer's temporal attention, tome/patch/timesformer.py:25-27: the host model's
+    softmax(q k^T * scale) v over the T <= 8 copies of a spatial token) against the fp32 expression, q / k / v read in
+    place from one qkv projection; the framework's fused attention on the same views gives the second opinion."""
+    from tome import _abi
+    g = torch.Generator(device=DEV).manual_seed(B * 31 + H * 7 + N)
+    qkv = torch.randn(B, N, 3, H, 64, device=DEV, generator=g).to(dtype)
+    qkv[:, :, 0] *= 3.0  # (peaky softmax rows as well as flat ones)
+    q, k, v = qkv.permute(2, 0, 3, 1, 4)
+    assert _abi.short_attention_ok(q, k, v)
+    out = _abi.short_attention(q, k, v, 0.125)
+    assert out.shape == (B, N, H * 64) and out.dtype == dtype and out.is_contiguous()
+    att = (q.float() @ k.float().transpose(-2, -1) * 0.125).softmax(dim=-1)
+    want = (att @ v.float()).transpose(1, 2).reshape(B, N, H * 64)
+    # the result is rounded once to the 16-bit format (tol = one ulp, relative) on top of fp32 arithmetic
+    excess = (out.float() - want).abs() - (tol * want.abs() + 1e-3)
+    assert float(excess.max()) <= 0.0, float(excess.max())
+    sdpa = torch.nn.functional.scaled_dot_product_attention(q, k, v, scale=0.125).transpose(1, 2).reshape(B, N, H * 64)
+    excess = (out.float() - sdpa.float()).abs() - (3 * tol * want.abs() + 4e-3)  # (the framework rounds P to 16 bits)
+    assert float(excess.max()) <= 0.0, float(excess.max())
+
+
+def test_short_attention_refuses_what_it_cannot_do():
+    from tome import _abi
+    qkv = torch.randn(4, 9, 3, 2, 64, device=DEV).bfloat16()
+    q, k, v = qkv.permute(2, 0, 3, 1, 4)
+    assert not _abi.short_attention_ok(q, k, v)  # nine tokens
+    with pytest.raises(_abi.TomeHipError):
+        _abi.short_attention(q, k, v, 0.125)
+    heads_first = torch.randn(4, 2, 8, 64, device=DEV).bfloat16()  # [B, H, N, 64] contiguous: head stride N * 64
+    assert not _abi.short_attention_ok(heads_first, heads_first, heads_first)
+    ok = torch.randn(4, 8, 3, 2, 64, device=DEV).bfloat16().permute(2, 0, 3, 1, 4)
+    assert not _abi.short_attention_ok(ok[0].float(), ok[1].float(), ok[2].float())
+    assert not _abi.short_attention_ok(ok[0].cpu(), ok[1].cpu(), ok[2].cpu())
+
+
 @pytest.mark.parametrize("growth", [0.05, 1.0, 40.0])
 @pytest.mark.parametrize("dtype,tol", [(torch.bfloat16, 2e-2), (torch.float16, 4e-3)])
 def test_prop_attention_running_maximum_moves(growth, dtype, tol):

@@ -79,7 +79,7 @@ class _CallCounter:
     """Counts calls of the fused entry points of tome._abi during a forward (is the production path the one
     that ran?)."""
     NAMES = ("match_keys", "match", "prop_attention", "merge_wavg_ln", "merge_wavg_regrouped", "merge_wavg",
-             "add_layernorm", "trajectory_mix")
+             "add_layernorm", "trajectory_mix", "short_attention")
 
     def __init__(self, monkeypatch):
         from tome import _abi
@@ -194,6 +194,8 @@ def _assert_production_calls(calls, meta, n_layers):
         assert calls.n["match_keys"] == n_layers and calls.n["match"] == 0, calls.n
     if meta["host"] == "motionformer":
         assert calls.n["trajectory_mix"] > 0, calls.n
+    if meta["host"] == "timesformer":  # the temporal attention of every divided space-time block
+        assert calls.n["short_attention"] >= n_layers, calls.n
     if not meta.get("duplicate"):  # (a duplicate block only attends and merges: no LayerNorm behind that merge)
         fused = calls.n["merge_wavg_ln"] + calls.n["merge_wavg_regrouped"]
         assert fused == n_layers and calls.n["merge_wavg"] == 0, calls.n

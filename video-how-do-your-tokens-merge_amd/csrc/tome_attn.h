@@ -656,3 +656,104 @@ __global__ __launch_bounds__(256) void k_trajectory_mix(const TX *__restrict__ q
         if (on) store_pack<TX, 8>(orow + 8 * c, acc[i]);
     }
 }
+
+// ------------------------------------------------------------------------------------------------
+// k_short_attention: attention over sequences of at most 8 tokens -- TimeSformer's temporal attention, the T copies of
+// one spatial token (ToMeBlock.forward, tome/patch/timesformer.py:25-27: self.temporal_attn on 'b (p t) m ->
+// (b p) t m'; the module is the host model's softmax(q k^T * scale) v).  Thousands of 8 x 8 problems per launch: no
+// matrix pipe, HBM bound (q, k, v read once from the qkv buffer in place, out written once as [B, N, H*64]).
+// Eight lanes own one (sequence, head): lane c holds channels 8c .. 8c+7 of every token's q, k and v row (3 x N
+// 16-byte loads, all issued before use); the N x N logits are packed 2-element dot products (v_dot2: exact products,
+// fp32 sums) reduced over the eight lanes by xor-shuffles; softmax and the weighted sum of v in fp32.
+// ------------------------------------------------------------------------------------------------
+#define SHORT_MAXN 8
+typedef __bf16 short_bf16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 short_f16x2 __attribute__((ext_vector_type(2)));
+template <typename TX> __device__ __forceinline__ float short_dot8(const uint4 &x, const uint4 &y);
+template <> __device__ __forceinline__ float short_dot8<bf16_t>(const uint4 &x, const uint4 &y) {
+    const uint32_t a[4] = {x.x, x.y, x.z, x.w}, b[4] = {y.x, y.y, y.z, y.w};
+    float t = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        short_bf16x2 p, q;
+        __builtin_memcpy(&p, &a[i], 4);
+        __builtin_memcpy(&q, &b[i], 4);
+        t = __builtin_amdgcn_fdot2_f32_bf16(p, q, t, false);
+    }
+    return t;
+}
+template <> __device__ __forceinline__ float short_dot8<f16_t>(const uint4 &x, const uint4 &y) {
+    const uint32_t a[4] = {x.x, x.y, x.z, x.w}, b[4] = {y.x, y.y, y.z, y.w};
+    float t = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        short_f16x2 p, q;
+        __builtin_memcpy(&p, &a[i], 4);
+        __builtin_memcpy(&q, &b[i], 4);
+        t = __builtin_amdgcn_fdot2(p, q, t, false);
+    }
+    return t;
+}
+
+template <typename TX>
+__global__ __launch_bounds__(256) void k_short_attention(const TX *__restrict__ q, const TX *__restrict__ k,
+                                                         const TX *__restrict__ v, int64_t q_sb, int64_t q_sn,
+                                                         int64_t k_sb, int64_t k_sn, int64_t v_sb, int64_t v_sn,
+                                                         int64_t units, int H, int N, float scale,
+                                                         TX *__restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t unit = ((int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 8 + (lane >> 3);
+    const bool on = unit < units;
+    const int64_t u = on ? unit : units - 1;  // (a lane past the end repeats the last unit's loads, stores nothing)
+    const int64_t b = u / H;
+    const int h = (int)(u - b * H);
+    const int ch = h * 64 + 8 * (lane & 7);
+    const TX *qr = q + b * q_sb + ch, *kr = k + b * k_sb + ch, *vr = v + b * v_sb + ch;
+    uint4 qraw[SHORT_MAXN], kraw[SHORT_MAXN], vraw[SHORT_MAXN];
+#pragma unroll
+    for (int t = 0; t < SHORT_MAXN; ++t) {
+        const int tt = t < N ? t : N - 1;  // (wave-uniform; a token past the end repeats the last one, masked below)
+        qraw[t] = traj_ld16(qr + tt * q_sn);
+        kraw[t] = traj_ld16(kr + tt * k_sn);
+    }
+#pragma unroll
+    for (int t = 0; t < SHORT_MAXN; ++t) vraw[t] = traj_ld16(vr + (t < N ? t : N - 1) * v_sn);
+    const float LOG2E = 1.4426950408889634f;
+    const float sl = scale * LOG2E;
+    TX *orow = out + (b * N) * ((int64_t)H * 64) + ch;
+#pragma unroll
+    for (int i = 0; i < SHORT_MAXN; ++i) {
+        if (i >= N) break;  // (wave-uniform)
+        float d[SHORT_MAXN];
+#pragma unroll
+        for (int j = 0; j < SHORT_MAXN; ++j) {
+            float t = short_dot8<TX>(qraw[i], kraw[j]);
+            t += __shfl_xor(t, 1);
+            t += __shfl_xor(t, 2);
+            t += __shfl_xor(t, 4);
+            d[j] = j < N ? t * sl : -INFINITY;
+        }
+        float m = d[0];
+#pragma unroll
+        for (int j = 1; j < SHORT_MAXN; ++j) m = fmaxf(m, d[j]);
+        float sum = 0.0f;
+#pragma unroll
+        for (int j = 0; j < SHORT_MAXN; ++j) {
+            d[j] = __builtin_amdgcn_exp2f(d[j] - m);
+            sum += d[j];
+        }
+        const float inv = 1.0f / sum;
+        float acc[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = 0.0f;
+#pragma unroll
+        for (int j = 0; j < SHORT_MAXN; ++j) {
+            Pack<TX, 8> pv;
+            __builtin_memcpy(&pv, &vraw[j], 16);
+            const float w = d[j] * inv;  // (0 for a masked key)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] = __builtin_fmaf(w, to_f32(pv.e[e]), acc[e]);
+        }
+        if (on) store_pack<TX, 8>(orow + (int64_t)i * H * 64, acc);
+    }
+}

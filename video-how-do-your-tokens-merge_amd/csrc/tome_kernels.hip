@@ -996,6 +996,36 @@ extern "C" int tome_trajectory_mix(const void *q2, const void *k2, const void *v
     return check_launch("k_trajectory_mix");
 }
 
+extern "C" int tome_short_attention(const void *q, const void *k, const void *v, int dtype, int64_t B, int64_t H,
+                                    int64_t N, int64_t D, const int64_t *q_strides, const int64_t *k_strides,
+                                    const int64_t *v_strides, float scale, void *out, tome_stream_t stream) {
+    if (!q || !k || !v || !out || !q_strides || !k_strides || !v_strides || B <= 0 || H <= 0 || N <= 0)
+        return fail(TOME_EINVAL, "tome_short_attention: bad shape/pointer");
+    if (D != 64 || N > SHORT_MAXN)
+        return fail(TOME_EINVAL, "tome_short_attention: head dim 64 and at most %d tokens per sequence", SHORT_MAXN);
+    if (dtype != TOME_BF16 && dtype != TOME_F16) return fail(TOME_EINVAL, "tome_short_attention: 16-bit tensors only");
+    // {batch, head, token} element strides; the heads of a token lie side by side (head stride 64), rows 16-byte aligned
+    const int64_t *strides[3] = {q_strides, k_strides, v_strides};
+    for (int i = 0; i < 3; ++i)
+        if (strides[i][1] != 64 || strides[i][0] % 8 || strides[i][2] % 8)
+            return fail(TOME_EINVAL, "tome_short_attention: head stride must be 64, batch / token strides multiples of 8");
+    if (!aligned16(q) || !aligned16(k) || !aligned16(v) || !aligned16(out))
+        return fail(TOME_EINVAL, "tome_short_attention: rows must be 16-byte aligned");
+    const int64_t units = B * H;  // (sequence, head) pairs, eight lanes each
+    const int64_t blocks = (units + 31) / 32;
+    if (blocks > 0x7fffffffLL) return fail(TOME_EINVAL, "tome_short_attention: too many sequences");
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == TOME_BF16)
+        hipLaunchKernelGGL(k_short_attention<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, st, (const bf16_t *)q,
+                           (const bf16_t *)k, (const bf16_t *)v, q_strides[0], q_strides[2], k_strides[0], k_strides[2],
+                           v_strides[0], v_strides[2], units, (int)H, (int)N, scale, (bf16_t *)out);
+    else
+        hipLaunchKernelGGL(k_short_attention<f16_t>, dim3((unsigned)blocks), dim3(256), 0, st, (const f16_t *)q,
+                           (const f16_t *)k, (const f16_t *)v, q_strides[0], q_strides[2], k_strides[0], k_strides[2],
+                           v_strides[0], v_strides[2], units, (int)H, (int)N, scale, (f16_t *)out);
+    return check_launch("k_short_attention");
+}
+
 extern "C" int tome_gelu_erf(const void *x, int dtype, int64_t elements, void *y, tome_stream_t stream) {
     if (!x || !y || elements <= 0) return fail(TOME_EINVAL, "tome_gelu_erf: bad shape/pointer");
     if (dtype != TOME_BF16 && dtype != TOME_F16) return fail(TOME_EINVAL, "tome_gelu_erf: 16-bit tensors only");

@@ -3,11 +3,16 @@ Conv2d patches, class token, learned space + time embeddings, divided space-time
 after the class token is patch-major: index 1 + p*T + t.  Parameter names match the reference."""
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
 from ._patchify import patch_tokens, tubelet_tokens  # noqa: F401
+from tome import _abi
+
+_SHORT_KERNEL = os.environ.get("TOME_SHORT_ATTN", "1") != "0"  # 0 = the framework's attention for the temporal stage
 
 
 class Mlp(nn.Module):
@@ -40,7 +45,13 @@ class Attention(nn.Module):
             q, k, v = self.qkv(x).reshape(B, N, 3, self.num_heads, C // self.num_heads).permute(2, 0, 3, 1, 4)
         else:
             q = k = v = x.reshape(B, N, self.num_heads, C // self.num_heads).permute(0, 2, 1, 3)
-        x = F.scaled_dot_product_attention(q, k, v, scale=self.scale).transpose(1, 2).reshape(B, N, C)
+        if N <= 8 and _SHORT_KERNEL and q.is_cuda and not (self.training and self.attn_drop.p > 0.0) \
+                and _abi.short_attention_ok(q, k, v):
+            # the temporal attention: thousands of sequences of T <= 8 tokens -- one streaming pass over q, k, v
+            # (tome_short_attention: 5 TB/s; the framework's fused attention + the head transpose run at 2.8)
+            x = _abi.short_attention(q, k, v, self.scale)
+        else:
+            x = F.scaled_dot_product_attention(q, k, v, scale=self.scale).transpose(1, 2).reshape(B, N, C)
         return self.proj_drop(self.proj(x)) if self.with_qkv else x
 
 

@@ -18,7 +18,7 @@ SYMBOLS = (
     "tome_abi_version", "tome_last_error", "tome_effective_r", "tome_match_workspace_bytes", "tome_match",
     "tome_match_keys",
     "tome_match_scores", "tome_edge_keep", "tome_merge_wavg", "tome_merge_wavg_ln", "tome_merge_wavg_regrouped",
-    "tome_merge_wavg_regrouped_ln", "tome_add_layernorm", "tome_add_layernorm_skip_first", "tome_add_layernorm_regrouped", "tome_prop_attention", "tome_prop_attention_segments", "tome_trajectory_mix", "tome_merge",
+    "tome_merge_wavg_regrouped_ln", "tome_add_layernorm", "tome_add_layernorm_skip_first", "tome_add_layernorm_regrouped", "tome_prop_attention", "tome_prop_attention_segments", "tome_trajectory_mix", "tome_short_attention", "tome_merge",
     "tome_drop",
     "tome_drop_regrouped",
     "tome_unmerge", "tome_row_map", "tome_source_init", "tome_gelu_erf",
@@ -96,6 +96,8 @@ def bind(path: str) -> ctypes.CDLL:
     L.tome_prop_attention_segments.restype = i32
     L.tome_prop_attention_segments.argtypes = [vp, vp, vp, i32, i64, i64, i64, i64, i64, vp, vp, vp, vp, i64,
                                                ctypes.c_float, vp, vp, i64, vp, vp]
+    L.tome_short_attention.restype = i32
+    L.tome_short_attention.argtypes = [vp, vp, vp, i32, i64, i64, i64, i64, vp, vp, vp, ctypes.c_float, vp, vp]
     L.tome_trajectory_mix.restype = i32
     L.tome_trajectory_mix.argtypes = [vp, vp, vp, i32, i64, i64, i64, i64, i64, i64, i64, ctypes.c_float, vp, i64, vp, vp]
     L.tome_drop_regrouped.restype = i32
@@ -683,6 +685,36 @@ def prop_attention_segments(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, n
                                                 y.data_ptr(), ostr, nseg, seg, _stream(q.device))
     _check(rc, "tome_prop_attention_segments")
     return y
+
+
+def short_attention_ok(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor) -> bool:
+    """Can tome_short_attention take these?  [B, H, N <= 8, 64] views of 16-bit device tensors whose heads lie side
+    by side in a token's row (head stride 64), rows 16-byte aligned, no gradient wanted."""
+    def ok(t):
+        return (t.is_cuda and t.dim() == 4 and t.shape == q.shape and t.dtype == q.dtype and t.device == q.device
+                and t.stride(3) == 1 and t.stride(1) == 64 and t.stride(0) % 8 == 0 and t.stride(2) % 8 == 0
+                and t.data_ptr() % 16 == 0 and not (torch.is_grad_enabled() and t.requires_grad))
+    return (q.dim() == 4 and q.dtype in (torch.bfloat16, torch.float16) and q.shape[-1] == 64 and 1 <= q.shape[2] <= 8
+            and ok(q) and ok(k) and ok(v))
+
+
+def short_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: float) -> torch.Tensor:
+    """softmax(q k^T * scale) v over sequences of at most 8 tokens (TimeSformer's temporal attention): q, k, v
+    [B, H, N, 64] views of one qkv projection, read in place; returns [B, N, H*64]."""
+    for t, name in ((q, "q"), (k, "k"), (v, "v")):
+        require_device(t, f"short_attention({name})")
+    if not short_attention_ok(q, k, v):
+        raise TomeHipError(f"short_attention: q, k, v must be [B, H, N <= 8, 64] 16-bit views with head stride 64 and "
+                           f"16-byte aligned rows, got {tuple(q.shape)} {q.dtype} strides {q.stride()}")
+    B, H, N, D = q.shape
+    out = torch.empty((B, N, H * D), dtype=q.dtype, device=q.device)
+    strides = [(ctypes.c_int64 * 3)(*t.stride()[:3]) for t in (q, k, v)]
+    with _on_device(q.device):
+        rc = lib().tome_short_attention(q.data_ptr(), k.data_ptr(), v.data_ptr(), dtype_code(q, "q"), B, H, N, D,
+                                        strides[0], strides[1], strides[2], float(scale), out.data_ptr(),
+                                        _stream(q.device))
+    _check(rc, "tome_short_attention")
+    return out
 
 
 def trajectory_mix_ok(q2: torch.Tensor, k2: torch.Tensor, val: torch.Tensor, heads: int) -> bool:
