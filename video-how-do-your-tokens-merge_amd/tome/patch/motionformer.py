@@ -4,12 +4,16 @@
 section 7.5), the class token is kept aside.  apply_patch takes the model itself."""
 from __future__ import annotations
 
+import os
+
 import torch
 from einops import rearrange
 
 from . import _common as C
 from .. import _abi
 from ..merge import HeadMeanKeys
+
+_JOIN = os.environ.get("TOME_TRAJ_JOIN", "1") != "0"  # 0 = class row and trajectory rows through torch.cat (measurement switch)
 
 
 def _block_forward(self, x, seq_len=196, num_frames=8, approx="none", num_landmarks=128):
@@ -56,9 +60,9 @@ def _trajectory_forward(self, x, seq_len=196, num_frames=8, approx="none", num_l
         # the class token attends to every token, sizes ignored (motionformer.py:54): the attention kernel with one
         # query per head, read in place
         # (its row is row 0 of the buffer the temporal stage fills below: cat((cls_out, x), dim=1) without the copy)
-        joined = torch.empty((B, N, h * hd), dtype=qkv.dtype, device=qkv.device)
+        joined = torch.empty((B, N, h * hd), dtype=qkv.dtype, device=qkv.device) if _JOIN else None
         cls_out = _abi.prop_attention(heads[0][:, :, :1], heads[1], heads[2], None, self.scale,
-                                      out=joined[:, :1].unflatten(2, (h, hd)))
+                                      out=joined[:, :1].unflatten(2, (h, hd)) if _JOIN else None)
         # every token attends to the P keys of ONE frame at a time (softmax per frame): ONE launch of the segmented
         # attention kernel, queries and keys read in place from the qkv buffer, segment f writing its slice of
         # y 'b s f (h d)'; the [B*h, N, N] logits, their softmax and the attn @ v product never exist
@@ -89,10 +93,11 @@ def _trajectory_forward(self, x, seq_len=196, num_frames=8, approx="none", num_l
         # F logits per (token, head), their softmax and the weighted sum of the F trajectory tokens: one streaming
         # pass over k2 and val (tome_trajectory_mix) instead of two multiplies, two reductions and a softmax
         out, tattn = _abi.trajectory_mix(q2p, kv[..., :Cc], val_tok, h, self.scale, want_attn=_want_attn,
-                                         out=joined[:, 1:])
+                                         out=joined[:, 1:] if _JOIN else None)
         if tattn is not None:
             tattn = tattn.to(x.dtype)
-        out = joined  # class row + trajectory rows, already side by side
+        # class row + trajectory rows, already side by side
+        out = joined if _JOIN else torch.cat((cls_out.reshape(B, 1, -1), out), dim=1)
     else:
         q2 = rearrange(q2p, "b s (h d) -> b h s d", h=h) * self.scale
         k2 = rearrange(kv[..., :Cc], "b s f (h d) -> b h s f d", f=F, h=h)
