@@ -194,7 +194,8 @@ def _assert_production_calls(calls, meta, n_layers):
         assert calls.n["match_keys"] == n_layers and calls.n["match"] == 0, calls.n
     if meta["host"] == "motionformer":
         assert calls.n["trajectory_mix"] > 0, calls.n
-    if meta["host"] == "timesformer":  # the temporal attention of every divided space-time block
+    from hosts import timesformer as ts_host
+    if meta["host"] == "timesformer" and ts_host._SHORT_KERNEL:  # the temporal attention of every space-time block
         assert calls.n["short_attention"] >= n_layers, calls.n
     if not meta.get("duplicate"):  # (a duplicate block only attends and merges: no LayerNorm behind that merge)
         fused = calls.n["merge_wavg_ln"] + calls.n["merge_wavg_regrouped"]
@@ -730,6 +731,8 @@ def test_block_output_with_and_without_the_fc2_fold_bf16(host_name, monkeypatch)
     largest magnitude of that output row... and the fold must actually have been taken and consumed (`_folded`)."""
     tome, H = _hosts()
     from tome.patch import _common
+    if not all((_common._FUSE_LN, _common._FUSE_ADD, _common._FUSE_NEXT)):
+        pytest.skip("the fold rides on the fused merge + LayerNorm hand-over, which a TOME_FUSE_* switch has turned off")
     torch.manual_seed(0)
     if host_name == "videomae":
         model = H["videomae"].VideoMAE(num_frames=8, img_size=64, patch_size=16, embed_dim=128, depth=3, num_heads=2,
