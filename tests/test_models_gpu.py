@@ -617,6 +617,50 @@ def test_attention_kernel_equals_framework_attention_bf16(host_name, monkeypatch
     assert float((o1 - o0).abs().max()) <= 0.05 * max(1.0, float(o0.abs().max()))
 
 
+@pytest.mark.parametrize("original", [True, False])
+def test_motionformer_key_half_of_proj_kv(original, monkeypatch):
+    """use_original_code (the reference's default) sums over the trajectory tokens themselves: the value half of proj_kv
+    is computed and never read (tome/patch/motionformer.py:123,130-134).  The patch then evaluates only the key half --
+    the proj_kv MODULE is not called, the attention output matches the full projection's within bf16 rounding of one
+    GEMM -- and with use_original_code=False it calls the module as the reference does."""
+    tome, H = _hosts()
+    import sys
+    mf_patch = sys.modules["tome.patch.motionformer"]  # (tome.patch.motionformer the NAME is apply_patch, as in the reference)
+    torch.manual_seed(0)
+    model = H["motionformer"].Motionformer(img_size=64, patch_size=8, patch_size_temp=2, temporal_resolution=4,
+                                           embed_dim=128, depth=2, num_heads=2, num_classes=9, use_original_code=original)
+    model = model.to(DEV).to(torch.bfloat16).eval()
+    tome.patch.motionformer(model, prop_attn=True)
+    model.r = 4
+    clip = [torch.rand(2, 3, 8, 64, 64, device=DEV).to(torch.bfloat16)]
+    calls = []
+    hooks = [b.attn.proj_kv.register_forward_pre_hook(lambda m, i: calls.append(1)) for b in model.blocks]
+    with torch.no_grad():
+        model(clip)
+    # (a hooked module is not "stock": its forward must run -- the hand-made call is refused, for both settings)
+    assert len(calls) == len(model.blocks)
+    for hk in hooks:
+        hk.remove()
+    outs = {}
+    for keys_only in (True, False):
+        monkeypatch.setattr(mf_patch, "_KEYS_ONLY", keys_only)
+        seen = []
+        real = torch.nn.Linear.forward
+
+        def spy(self, x, real=real, seen=seen):
+            if any(self is b.attn.proj_kv for b in model.blocks):
+                seen.append(1)
+            return real(self, x)
+        monkeypatch.setattr(torch.nn.Linear, "forward", spy)
+        with torch.no_grad():
+            outs[keys_only] = (model(clip).float(), len(seen))
+        monkeypatch.setattr(torch.nn.Linear, "forward", real)
+    (o1, n1), (o0, n0) = outs[True], outs[False]
+    assert n0 == len(model.blocks)
+    assert n1 == (0 if original else len(model.blocks)), (original, n1)
+    assert float((o1 - o0).abs().max()) <= 0.02 * max(1.0, float(o0.abs().max()))
+
+
 _CFG_YAML = """\
 TRAIN:
   ENABLE: True

@@ -75,8 +75,14 @@ def trajectory_attention(mod, x, P, F, approx="none", size=None):
     y_diag = torch.diagonal(y_diag, dim1=-4, dim2=-2)
     y_diag = rearrange(y_diag, "b n d f -> b (f n) d", f=F)
     q2 = rearrange(mod.proj_q(y_diag), "b s (h d) -> b h s d", h=h) * mod.scale
-    k2, v2 = mod.proj_kv(y).chunk(2, dim=-1)
-    k2, v2 = (rearrange(t, "b s f (h d) -> b h s f d", f=F, h=h) for t in (k2, v2))
+    if mod.use_original_code and type(mod.proj_kv) is nn.Linear and not mod.proj_kv._forward_hooks:
+        # v2 is never read on this setting (the sum below runs over y): only the key half of the projection
+        pb = mod.proj_kv.bias
+        k2 = torch.nn.functional.linear(y, mod.proj_kv.weight[:C], None if pb is None else pb[:C])
+        k2, v2 = rearrange(k2, "b s f (h d) -> b h s f d", f=F, h=h), None
+    else:
+        k2, v2 = mod.proj_kv(y).chunk(2, dim=-1)
+        k2, v2 = (rearrange(t, "b s f (h d) -> b h s f d", f=F, h=h) for t in (k2, v2))
     # F = 8 logits per trajectory: a broadcast multiply + reduction streams k2 once; as the batched
     # [1 x d] @ [d x F] products the einsum form lowers to, it is the slowest kernel of the model on MI355X
     tattn = (k2 * q2.unsqueeze(-2)).sum(dim=-1).softmax(dim=-1)

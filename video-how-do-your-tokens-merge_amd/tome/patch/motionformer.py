@@ -13,6 +13,7 @@ from . import _common as C
 from .. import _abi
 from ..merge import HeadMeanKeys
 
+_KEYS_ONLY = os.environ.get("TOME_TRAJ_KEYS_ONLY", "1") != "0"  # 0 = evaluate all of proj_kv even when v2 is unused
 _JOIN = os.environ.get("TOME_TRAJ_JOIN", "1") != "0"  # 0 = class row and trajectory rows through torch.cat (measurement switch)
 
 
@@ -86,13 +87,22 @@ def _trajectory_forward(self, x, seq_len=196, num_frames=8, approx="none", num_l
     y_diag = torch.diagonal(y_diag, dim1=-4, dim2=-2)
     y_diag = rearrange(y_diag, "b n d f -> b (f n) d", f=F)
     q2p = self.proj_q(y_diag)  # [B, S, C]
-    kv = self.proj_kv(y)       # [B, S, F, 2C]: keys | values
     Cc = q2p.shape[-1]
-    val_tok = y if self.use_original_code else kv[..., Cc:]
-    if fused and _abi.trajectory_mix_ok(q2p, kv[..., :Cc], val_tok, h):
+    if self.use_original_code and _KEYS_ONLY and C._stock_module(self.proj_kv, torch.nn.Linear):
+        # use_original_code (the reference's default): the weighted sum runs over the trajectory tokens y themselves,
+        # v2 -- the second half of proj_kv's output -- is computed and never read (motionformer.py:123,130-134).  Only
+        # the key half of the projection is evaluated: half of the model's largest GEMM ([B*S*F, C] x [C, 2C]).
+        pb = self.proj_kv.bias
+        k2_tok = torch.nn.functional.linear(y, self.proj_kv.weight[:Cc], None if pb is None else pb[:Cc])
+        val_tok = y
+    else:
+        kv = self.proj_kv(y)       # [B, S, F, 2C]: keys | values
+        k2_tok = kv[..., :Cc]
+        val_tok = y if self.use_original_code else kv[..., Cc:]
+    if fused and _abi.trajectory_mix_ok(q2p, k2_tok, val_tok, h):
         # F logits per (token, head), their softmax and the weighted sum of the F trajectory tokens: one streaming
         # pass over k2 and val (tome_trajectory_mix) instead of two multiplies, two reductions and a softmax
-        out, tattn = _abi.trajectory_mix(q2p, kv[..., :Cc], val_tok, h, self.scale, want_attn=_want_attn,
+        out, tattn = _abi.trajectory_mix(q2p, k2_tok, val_tok, h, self.scale, want_attn=_want_attn,
                                          out=joined[:, 1:] if _JOIN else None)
         if tattn is not None:
             tattn = tattn.to(x.dtype)
@@ -100,7 +110,7 @@ def _trajectory_forward(self, x, seq_len=196, num_frames=8, approx="none", num_l
         out = joined if _JOIN else torch.cat((cls_out.reshape(B, 1, -1), out), dim=1)
     else:
         q2 = rearrange(q2p, "b s (h d) -> b h s d", h=h) * self.scale
-        k2 = rearrange(kv[..., :Cc], "b s f (h d) -> b h s f d", f=F, h=h)
+        k2 = rearrange(k2_tok, "b s f (h d) -> b h s f d", f=F, h=h)
         # F = 8 logits per trajectory: a broadcast multiply + reduction streams k2 once; as the batched
         # [1 x d] @ [d x F] products the einsum form lowers to, it is the slowest kernel of the model on MI355X
         tattn = (k2 * q2.unsqueeze(-2)).sum(dim=-1).softmax(dim=-1)
