@@ -396,6 +396,46 @@ def test_vivit_duplicate_layer_patch(dtype):
     assert torch.equal(want, got)
 
 
+def test_vivit_fused_qkv_projection_follows_its_weights(monkeypatch):
+    """The ViViT patch runs query / key / value (tome/patch/vivit.py:95-101 of the reference: three Linear calls) as one
+    projection over a cached side-by-side copy of the three weights.  The cached copy must follow the weights (in-place
+    update, replaced parameter), hooked or grad-enabled modules must run themselves, and the result must match the three
+    separate GEMMs within the rounding of a GEMM of another shape."""
+    tome, H = _hosts()
+    import sys
+    vv = sys.modules["tome.patch.vivit"]
+    torch.manual_seed(0)
+    model = H["vivit"].ViViT(num_classes=5, image_size=64, num_frames=8, hidden_size=128, num_hidden_layers=2,
+                             num_attention_heads=2, intermediate_size=256).to(DEV).to(torch.bfloat16).eval()
+    tome.patch.vivit(model)
+    model.r = 6
+    clip = [torch.rand(2, 3, 8, 64, 64, device=DEV).to(torch.bfloat16)]
+    att = model.vivit.encoder.layer[0].attention.attention
+
+    def run(fused):
+        monkeypatch.setattr(vv, "_FUSE_QKV", fused)
+        with torch.no_grad():
+            return model(clip).float()
+
+    a, b = run(True), run(False)
+    assert "_tome_qkv" in att.__dict__ and "_tome_qkv" not in model.state_dict()
+    assert float((a - b).abs().max()) <= 0.02 * max(1.0, float(b.abs().max()))
+    with torch.no_grad():
+        att.query.weight.mul_(-1.0)  # in place: the version counter moves, the cached copy must be rebuilt
+    a2, b2 = run(True), run(False)
+    assert float((a2 - b2).abs().max()) <= 0.02 * max(1.0, float(b2.abs().max()))
+    assert float((a2 - a).abs().max()) > 0.0
+    att.key.weight = torch.nn.Parameter(att.key.weight.detach().clone() * 0.5, requires_grad=False)  # replaced
+    a3, b3 = run(True), run(False)
+    assert float((a3 - b3).abs().max()) <= 0.02 * max(1.0, float(b3.abs().max()))
+    # a hooked projection runs itself
+    seen = []
+    hk = att.value.register_forward_hook(lambda m, i, o: seen.append(1))
+    run(True)
+    hk.remove()
+    assert len(seen) == 1
+
+
 def test_graphed_forward_replays_the_merge_path():
     """The whole patched forward, merge kernels included, captured in a HIP graph and replayed on new clips:
     same logits as the eager run (the merge path launches on torch's current stream, allocates through

@@ -5,6 +5,7 @@ from __future__ import annotations
 
 import copy
 import math
+import os
 
 import torch
 import torch.nn.functional as F
@@ -12,6 +13,8 @@ import torch.nn.functional as F
 from . import _common as C
 from .. import _abi
 from ..merge import HeadMeanKeys
+
+_FUSE_QKV = os.environ.get("TOME_VIVIT_QKV", "1") != "0"  # 0 = three separate query / key / value GEMMs (measurement switch)
 
 
 def _layer_forward(self, hidden_states, head_mask=None, output_attentions=False):
@@ -64,7 +67,14 @@ def _self_attention_forward(self, hidden_states, size=None, head_aggregation="me
     def heads(t):
         return t.view(B, N, H, hd).permute(0, 2, 1, 3)
 
-    q, k, v = heads(self.query(hidden_states)), heads(self.key(hidden_states)), heads(self.value(hidden_states))
+    qkv_w = _fused_qkv(self, hidden_states)
+    if qkv_w is not None:
+        # query / key / value as ONE projection (the three weight matrices side by side, cached per module and
+        # rebuilt when any of them changes): one [B*N, C] x [C, 3C] GEMM instead of three [C, C] ones; q, k, v stay
+        # strided views of its output, which the attention and matching kernels read in place
+        q, k, v = torch.nn.functional.linear(hidden_states, qkv_w[0], qkv_w[1]).view(B, N, 3, H, hd).permute(2, 0, 3, 1, 4)
+    else:
+        q, k, v = heads(self.query(hidden_states)), heads(self.key(hidden_states)), heads(self.value(hidden_states))
     probs = None
     if output_attentions or head_mask is not None:
         scores = torch.matmul(q, k.transpose(-1, -2)) / math.sqrt(hd)
@@ -84,6 +94,29 @@ def _self_attention_forward(self, hidden_states, size=None, head_aggregation="me
     else:
         raise ValueError(f"head_aggregation {head_aggregation!r}")
     return (ctx, metric, probs) if output_attentions else (ctx, metric)
+
+
+def _fused_qkv(self, hidden_states):
+    """(weight [3C, C], bias [3C] or None) of the module's query / key / value projections side by side, or None when
+    the three are not plain unhooked nn.Linear layers of one shape in inference on a 16-bit device tensor."""
+    lins = (self.query, self.key, self.value)
+    if not (_FUSE_QKV and hidden_states.is_cuda and hidden_states.dtype in (torch.bfloat16, torch.float16)
+            and not self.training and not torch.is_grad_enabled()
+            and all(C._stock_module(m, torch.nn.Linear) for m in lins)):
+        return None
+    ws = [m.weight for m in lins]
+    bs = [m.bias for m in lins]
+    if any(w.shape != ws[0].shape or w.dtype != hidden_states.dtype or w.device != hidden_states.device for w in ws) \
+            or len({b is None for b in bs}) != 1:
+        return None
+    key = tuple((t.data_ptr(), t._version) for t in ws + [b for b in bs if b is not None])
+    cached = self.__dict__.get("_tome_qkv")
+    if cached is None or cached[0] != key:
+        w = torch.cat([w.detach() for w in ws], dim=0)
+        b = None if bs[0] is None else torch.cat([b.detach() for b in bs], dim=0)
+        cached = (key, w, b)
+        self.__dict__["_tome_qkv"] = cached  # (not a parameter, not in the state_dict)
+    return cached[1], cached[2]
 
 
 def vivit_merge(metric, x, _tome_info):
