@@ -140,12 +140,24 @@ class VisionTransformer(nn.Module):
     def forward_features(self, x):
         B = x.shape[0]
         x, T, W = self.patch_embed(x)                       # [(B T), n, m]
-        x = torch.cat((self.cls_token.expand(x.size(0), -1, -1), x), dim=1) + self.pos_embed
-        if self.attention_type != "space_only":
-            cls = x[:B, 0, :].unsqueeze(1)
-            n = x.size(1) - 1
-            x = x[:, 1:].reshape(B, T, n, -1).transpose(1, 2).reshape(B * n, T, -1) + self.time_embed
-            x = torch.cat((cls, x.reshape(B, n * T, -1)), dim=1)
+        if self.attention_type != "space_only" and not (torch.is_grad_enabled() and x.requires_grad):
+            # cat(cls, x) + pos_embed, 'b t n -> b n t', + time_embed, cat(cls, x) of the reference -- the same sums
+            # in the same order (patch + pos, rounded, + time; cls + pos[0]) written straight into the token sequence
+            # [B, 1 + n*T, m]: two passes over the tokens instead of six
+            n, m = x.size(1), x.size(2)
+            seq = torch.empty((B, 1 + n * T, m), dtype=x.dtype, device=x.device)
+            body = seq[:, 1:].view(B, n, T, m)
+            torch.add(x.view(B, T, n, m).transpose(1, 2), self.pos_embed[:, 1:].view(1, n, 1, m), out=body)
+            body.add_(self.time_embed.view(1, 1, T, m))
+            seq[:, 0] = self.cls_token[:, 0] + self.pos_embed[:, 0]
+            x = seq
+        else:
+            x = torch.cat((self.cls_token.expand(x.size(0), -1, -1), x), dim=1) + self.pos_embed
+            if self.attention_type != "space_only":
+                cls = x[:B, 0, :].unsqueeze(1)
+                n = x.size(1) - 1
+                x = x[:, 1:].reshape(B, T, n, -1).transpose(1, 2).reshape(B * n, T, -1) + self.time_embed
+                x = torch.cat((cls, x.reshape(B, n * T, -1)), dim=1)
         for blk in self.blocks:
             x = blk(x, B, T, W)
         if self.attention_type == "space_only":
