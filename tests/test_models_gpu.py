@@ -51,27 +51,34 @@ def _build(meta):
 
 
 def _trace(tome, model, clip, r, keep_metric=False):
-    """Run the patched model, recording the plan of every matching (and, on request, the metric it saw)."""
+    """Run the patched model, recording the plan of every matching (and, on request, the metric it saw) -- whichever
+    of the three matching functions the patch's mode calls."""
     from tome.patch import _common
     plans = []
-    orig = _common.bipartite_soft_matching
+    names = ("bipartite_soft_matching", "bipartite_soft_matching_drop", "bipartite_soft_matching_hybrid")
+    originals = {k: getattr(_common, k) for k in names}
 
-    def spy(metric, r_, class_token=False, distill_token=False, mode="merge"):
-        merge, unmerge = orig(metric, r_, class_token, distill_token, mode)
-        if hasattr(merge, "plan"):
-            rec = (metric.shape, merge.plan)
-            if keep_metric:
-                m = metric.materialize() if hasattr(metric, "materialize") else metric
-                rec += (m.detach().double(),)
-            plans.append(rec)
-        return merge, unmerge
-    _common.bipartite_soft_matching = spy
+    def spy_of(orig):
+        def spy(metric, *a, **kw):
+            got = orig(metric, *a, **kw)
+            fn = got[0] if isinstance(got, tuple) else got
+            if hasattr(fn, "plan"):
+                rec = (metric.shape, fn.plan)
+                if keep_metric:
+                    m = metric.materialize() if hasattr(metric, "materialize") else metric
+                    rec += (m.detach().double(),)
+                plans.append(rec)
+            return got
+        return spy
+    for k in names:
+        setattr(_common, k, spy_of(originals[k]))
     try:
         model.r = r
         with torch.no_grad():
             out = model([clip])
     finally:
-        _common.bipartite_soft_matching = orig
+        for k in names:
+            setattr(_common, k, originals[k])
     return out, plans
 
 
@@ -152,7 +159,43 @@ def test_patched_model_matches_reference(meta, monkeypatch):
 
 
 _HD64 = [m for m in G.manifest()["models"] if m["cfg"]["embed_dim"] // m["cfg"]["num_heads"] == 64]
-BF16_LOGIT_TOL = 0.08  # of the largest |logit| of the fixture (measured: 0.4 % .. 5.3 %); see the docstring below
+BF16_LOGIT_TOL = 0.08  # ceiling for a fixture that has no measured value yet (of the largest |logit| of the fixture)
+
+
+def _measured():
+    """tests/golden/measured.json: per fixture, what a run on MI355X measured (bf16 / fp32 logit error against the
+    reference's logits, share of tokens in the reference's merged group per layer).  The tests hold a run to 1.5x the
+    measured error (and to the measured agreement minus 2 points) instead of one global tolerance; a run with
+    TOME_RECORD_MEASURED=1 writes what it sees to gpurun_out/measured_seen.json (tools/update_measured.py folds the
+    largest values of several runs into the tracked file)."""
+    path = os.path.join(G.GOLDEN, "measured.json")
+    if not os.path.exists(path):
+        return {}
+    import json
+    with open(path) as f:
+        return json.load(f)
+
+
+def _note_measured(name, **values):
+    if os.environ.get("TOME_RECORD_MEASURED") != "1":
+        return
+    import json
+    out = os.path.join(os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__)))),
+                       "gpurun_out", "measured_seen.json")
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    seen = json.load(open(out)) if os.path.exists(out) else {}
+    seen.setdefault(name, {}).update(values)
+    with open(out, "w") as f:
+        json.dump(seen, f, indent=1)
+
+
+def _logit_tol(name, key, scale, ceiling):
+    """1.5 x the error a run on MI355X measured for this fixture (never below 0.2 % of the largest |logit|: the last
+    bits of the library GEMMs differ between library builds), or `ceiling * scale` while no measurement is stored."""
+    m = _measured().get(name, {}).get(key)
+    if m is None:
+        return ceiling * scale
+    return max(1.5 * m, 2e-3 * scale)
 
 
 @pytest.mark.parametrize("meta", _HD64, ids=lambda m: m["name"])
@@ -236,9 +279,12 @@ def _check_layer0_and_logits(meta, z, plans32, plans16, out16):
         # l0_set_gap): every group's source SET is then above the 16-bit noise and has been compared
         assert checked_sets == want_src.shape[0], (checked_sets, noise, meta["l0_set_gap"])
     ref = z["logits"]
-    err = np.abs(out16.float().cpu().numpy() - ref).max()
-    print(f"{meta['name']}: bf16 logits max |diff| {err:.3e} (largest |logit| {np.abs(ref).max():.3e})")
-    assert err <= BF16_LOGIT_TOL * np.abs(ref).max(), (err, np.abs(ref).max())
+    err = float(np.abs(out16.float().cpu().numpy() - ref).max())
+    scale = float(np.abs(ref).max())
+    tol = _logit_tol(meta["name"], "bf16_logit_err", scale, BF16_LOGIT_TOL)
+    print(f"{meta['name']}: bf16 logits max |diff| {err:.3e} (largest |logit| {scale:.3e}, tolerance {tol:.3e})")
+    _note_measured(meta["name"], bf16_logit_err=err)
+    assert err <= tol, (err, tol, scale)
 
 
 def test_videomae_schedule_and_modes():
@@ -542,8 +588,149 @@ def test_config0_videomae_b_full_size_against_the_reference(monkeypatch):
     out16, plans16 = _trace(tome, model16, clip.bfloat16(), meta["r"])
     assert [s[1] for s, _ in plans16] == meta["tokens"]
     err16 = float(np.abs(out16.float().cpu().numpy() - z["logits"]).max())
-    print(f"config0 full size bf16: logits max |diff| {err16:.3e}")
-    assert err16 <= BF16_LOGIT_TOL * float(np.abs(z["logits"]).max()), err16
+    tol16 = _logit_tol("config0_videomae_b", "bf16_logit_err", float(np.abs(z["logits"]).max()), BF16_LOGIT_TOL)
+    print(f"config0 full size bf16: logits max |diff| {err16:.3e} (tolerance {tol16:.3e})")
+    _note_measured("config0_videomae_b", bf16_logit_err=err16, fp32_logit_err=err, agree=agree)
+    assert err16 <= tol16, (err16, tol16)
+
+
+def _full_metas():
+    return G.manifest().get("full", [])
+
+
+@pytest.mark.parametrize("meta", _full_metas(), ids=lambda m: m["name"])
+def test_full_size_config_against_the_reference(meta, monkeypatch):
+    """BASELINE.json configs[1] (the metric's own config: VideoMAE-B 16x224, r = 16), configs[2] (TimeSformer divST
+    8x224, r = 8 / 16 / 32 incl. the 196 -> ... -> 1 walk) and configs[4] (Motionformer 224 16x4, r = 16) AT FULL SIZE
+    against the REAL reference (tests/golden/generate_models.py emit_full: the reference's tome/patch/<family>.py over
+    its own slowfast model class, embed 768 / depth 12 / 12 heads, 2 synth.uniform01 clips, fill_parameters weights,
+    fp32, CPU, trace_source=True, the family's default prop_attn).  Random-init keys are nearly parallel, so decision
+    margins are small (1e-7 .. 1e-4); the fixture carries per-position fp64 certificates (tau = 2e-5, two orders above
+    what fp32 evaluation moves a cosine) and the test holds exactly what they define:
+      * tokens, r_eff and groups of every layer exactly;
+      * layer 0: the source SET of every group whose r-boundary is certified; src_idx at every certified position;
+        the destination of every source whose top-2 gap is certified; unm_idx at every certified position (and as a set
+        where the boundary is certified); the merged-group partition after layer 0 exactly for every group that is
+        fully certified;
+      * later layers (the order in which a layer emits its unmerged rows -- row maxima 1e-8 .. 1e-5 apart under the
+        reference's unstable argsort -- decides which tokens are even / odd in the next layer, so the reference itself
+        would merge other tokens on another machine): the share of original tokens whose merged group equals the
+        reference's, per layer, printed, and held to the share a run on MI355X measured minus 2 points
+        (tests/golden/measured.json; >= 0.5 while none is stored); sizes sum to the tokens of a group;
+      * fp32 logits within 1.5x the measured error; the same clips in bf16 through the production kernels (asserted by
+        call count): token trace exact, logits within 1.5x the measured bf16 error."""
+    z = np.load(os.path.join(G.GOLDEN, f"models_{meta['name']}.npz"))
+    tome, model, patch = _build(meta)
+    patch(model, prop_attn=meta["prop_attn"], trace_source=True)
+    clip = _clip(meta)
+    from tome.patch import _common
+    parts = []
+    real_ms = _common.merge_source
+
+    def spy_source(merge, x, source=None):
+        out = real_ms(merge, x, source)
+        if hasattr(merge, "plan"):
+            parts.append(_partition_of(out))
+        return out
+    monkeypatch.setattr(_common, "merge_source", spy_source)
+    out, plans = _trace(tome, model, clip, meta["r"])
+    assert [s[1] for s, _ in plans] == meta["tokens"] and [p.r for _, p in plans] == meta["r_eff"]
+    assert [s[0] for s, _ in plans] == meta["groups"]
+    # ---- layer 0 against the certificates
+    p0 = plans[0][1]
+    got_src, got_dst, got_unm = (t.cpu().numpy()[..., 0] for t in (p0.src_idx, p0.dst_idx, p0.unm_idx))
+    want_src, want_dst, want_unm = (z[k].astype(np.int64) for k in ("L0_src", "L0_dst", "L0_unm"))
+    set_ok, src_ok, dst_ok, unm_ok = z["L0_set_ok"], z["L0_src_ok"], z["L0_dst_ok"], z["L0_unm_ok"]
+    np.testing.assert_array_equal(got_src[src_ok], want_src[src_ok], err_msg="layer 0 src_idx at certified positions")
+    np.testing.assert_array_equal(got_unm[unm_ok], want_unm[unm_ok], err_msg="layer 0 unm_idx at certified positions")
+    n_dst = 0
+    for g in range(want_src.shape[0]):
+        if set_ok[g]:
+            assert set(got_src[g].tolist()) == set(want_src[g].tolist()), f"group {g}: source set"
+            assert set(got_unm[g].tolist()) == set(want_unm[g].tolist()), f"group {g}: unmerged set"
+        got_map = dict(zip(got_src[g].tolist(), got_dst[g].tolist()))
+        for k, (i, j) in enumerate(zip(want_src[g].tolist(), want_dst[g].tolist())):
+            if dst_ok[g, k] and i in got_map:
+                assert got_map[i] == j, f"group {g}: destination of source row {i}"
+                n_dst += 1
+    assert n_dst >= int(dst_ok[set_ok].sum()) and n_dst > 0
+    group_ok = z["L0_group_ok"]
+    assert len(parts) == len(meta["tokens"])
+    np.testing.assert_array_equal(parts[0][group_ok], z["P0"][group_ok], err_msg="merged groups after layer 0")
+    agree = [float((got == z[f"P{layer}"]).mean()) for layer, got in enumerate(parts)]
+    exact = next((i for i, a in enumerate(agree) if a < 1.0), len(agree))
+    print(f"{meta['name']} fp32: layer 0 -- {int(set_ok.sum())}/{set_ok.size} source sets, {int(src_ok.sum())}/"
+          f"{src_ok.size} src positions, {n_dst}/{dst_ok.size} destinations, {int(unm_ok.sum())}/{unm_ok.size} unm "
+          f"positions, {int(group_ok.sum())}/{group_ok.size} group partitions certified, all equal to the reference; "
+          f"merged groups identical through layer {exact - 1}; share of original tokens in the reference's group per "
+          f"layer: {[round(a, 4) for a in agree]}")
+    known = _measured().get(meta["name"], {})
+    floor = [max(0.0, a - 0.02) for a in known["agree"]] if "agree" in known else [0.5] * len(agree)
+    assert all(a >= f for a, f in zip(agree, floor)), (agree, floor)
+    sizes = model._tome_info["size"].cpu().numpy()[..., 0]
+    t0 = meta["tokens"][0]
+    assert sizes.shape == z["size"].shape[:2] and (sizes.sum(1) == float(t0)).all()
+    assert (z["size"].sum((1, 2)) == float(t0)).all()
+    scale = float(np.abs(z["logits"]).max())
+    err = float(np.abs(out.cpu().numpy() - z["logits"]).max())
+    tol = _logit_tol(meta["name"], "fp32_logit_err", scale, 0.02)
+    print(f"{meta['name']} fp32: logits max |diff| {err:.3e} (largest |logit| {scale:.3e}, tolerance {tol:.3e})")
+    assert err <= tol, (err, tol)
+    # ---- the same clips as the benchmark runs them: bf16, every fused kernel on
+    monkeypatch.setattr(_common, "merge_source", real_ms)
+    del model
+    tome, model16, patch = _build(meta)
+    model16 = model16.to(torch.bfloat16)
+    patch(model16, prop_attn=meta["prop_attn"])
+    calls = _CallCounter(monkeypatch)
+    out16, plans16 = _trace(tome, model16, clip.bfloat16(), meta["r"])
+    assert [s[1] for s, _ in plans16] == meta["tokens"] and [p.r for _, p in plans16] == meta["r_eff"]
+    if all((_common._FUSE_LN, _common._FUSE_ADD, _common._FUSE_NEXT, _common._ATTN_KERNEL)):
+        _assert_production_calls(calls, meta, len(plans16))
+    err16 = float(np.abs(out16.float().cpu().numpy() - z["logits"]).max())
+    tol16 = _logit_tol(meta["name"], "bf16_logit_err", scale, BF16_LOGIT_TOL)
+    print(f"{meta['name']} bf16: logits max |diff| {err16:.3e} (tolerance {tol16:.3e})")
+    _note_measured(meta["name"], fp32_logit_err=err, bf16_logit_err=err16, agree=agree)
+    assert err16 <= tol16, (err16, tol16)
+
+
+@pytest.mark.parametrize("meta", G.manifest().get("modes", []), ids=lambda m: m["name"])
+def test_patch_level_drop_and_hybrid_against_the_reference(meta):
+    """The patch-level glue of the DROP and HYBRID modes against the reference's own patched models
+    (tome/patch/videomae.py:102-151, timesformer.py:111-185, motionformer.py:172-245; fixtures:
+    generate_models.py emit_mode, reduced width, head dim 64, trace_source=True, every layer certified): per layer
+    token counts, r_eff and the index tensors exactly; the sizes exactly -- drop resets them to ones of **fp32**
+    whatever the tokens' dtype (videomae.py:123), hybrid sums what the kept destinations and the sources carry; the
+    final source matrix exactly (drop: `drop(eye)`, a dropped token has no column entry; hybrid: a destination with an
+    incoming edge below the threshold loses its own column, merge.py:326-331); logits within 2e-4.  Hybrid fixtures
+    carry a threshold INSIDE the selected edges' scores (some destinations kept, some zeroed in every fixture:
+    `edges_kept` of `edges` in the manifest), plumbed through `_tome_info["threshold"]`, and the per-edge keep flags
+    of every layer are compared too."""
+    assert meta["certified"]
+    z = np.load(os.path.join(G.GOLDEN, f"models_{meta['name']}.npz"))
+    tome, model, patch = _build(meta)
+    kw = dict(prop_attn=meta["prop_attn"], mode=meta["mode"], trace_source=True)
+    if meta["mode"] == "hybrid":
+        kw["threshold"] = meta["threshold"]
+    patch(model, **kw)
+    info = model._tome_info
+    assert info["mode"] == meta["mode"] and info["trace_source"] is True
+    out, plans = _trace(tome, model, _clip(meta), meta["r"])
+    assert [s[1] for s, _ in plans] == meta["tokens"] and [p.r for _, p in plans] == meta["r_eff"]
+    assert [s[0] for s, _ in plans] == meta["groups"]
+    for i, (_, p) in enumerate(plans):
+        np.testing.assert_array_equal(p.src_idx.cpu().numpy()[..., 0], z[f"L{i}_src"], err_msg=f"layer {i} src")
+        np.testing.assert_array_equal(p.unm_idx.cpu().numpy()[..., 0], z[f"L{i}_unm"], err_msg=f"layer {i} unm")
+        if meta["mode"] == "hybrid":
+            np.testing.assert_array_equal(p.dst_idx.cpu().numpy()[..., 0], z[f"L{i}_dst"], err_msg=f"layer {i} dst")
+            keep = p.edge_keep.cpu().numpy().astype(bool).reshape(z[f"L{i}_keep"].shape)
+            np.testing.assert_array_equal(keep, z[f"L{i}_keep"], err_msg=f"layer {i} edge keep flags")
+            assert 0 < int(z["L0_keep"].sum()) < z["L0_keep"].size
+    size = info["size"]
+    assert str(size.dtype) == meta["size_dtype"]
+    np.testing.assert_array_equal(size.cpu().numpy(), z["size"])
+    np.testing.assert_array_equal(info["source"].cpu().numpy().astype(np.uint8), z["source"])
+    np.testing.assert_allclose(out.cpu().numpy(), z["logits"], atol=2e-4, rtol=1e-4)
 
 
 def test_config0_videomae_b_fp32_vs_cpu_port():

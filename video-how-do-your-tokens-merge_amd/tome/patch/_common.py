@@ -7,6 +7,7 @@ works on the reference's own model objects and on the host models of this reposi
 from __future__ import annotations
 
 import os
+import threading
 from typing import Callable, Dict, Tuple
 
 import torch
@@ -60,29 +61,58 @@ def new_tome_info(trace_source, prop_attn, mode, head_aggregation, threshold, ve
     }
 
 
-# One forward in flight per process.  Two patched (or unpatched) forwards issued on two HIP streams of one process never
-# finish on this platform: every GEMM of these models runs as hipBLASLt's persistent Stream-K kernel
-# (`Custom_Cijk_..._SK3_..._MT256x256x64`: one workgroup per CU, workgroups spin on each other's partial tiles), and two
-# such grids resident at once deadlock -- reproduced with two chains of plain `torch.mm` on two streams and nothing
-# else (tools/probes/two_stream_gemm.py: 88 ms on one stream, not finished after 20 s on two, with either BLAS
-# preference).  The reference's own contract is one forward at a time per model (`_tome_info` is shared state,
-# SURVEY 8b "Threading").  A patched forward issued while another one is still in flight on a different stream is
-# therefore ORDERED behind it (the stream waits for the other forward's end event; said once in a warning) instead of
-# hanging the device: two streams then buy no overlap, and nothing deadlocks.  TOME_ONE_FORWARD=raise refuses instead.
+# One forward in flight per process.  Two forwards (patched or not) issued on two HIP streams of one process never
+# finish on this platform: two chains of plain library GEMMs (`torch.mm`, nothing of this package) on two streams are
+# not finished after 20 s where one stream takes 88 ms (tools/probes/two_stream_gemm.py,
+# profiles/r03_two_stream_gemm_probe.txt) -- with either BLAS preference, so the cause is "two concurrent library GEMM
+# grids", not one particular kernel (see the probe's docstring for what the kernel trace of the finishing leg shows).
+# The reference's own contract is one forward at a time per model (`_tome_info` is shared state, SURVEY 8b
+# "Threading").  So: (1) the ENQUEUEING of a patched forward holds a per-device lock -- a second host thread that
+# starts a forward while the first is still issuing kernels (launches release the GIL) waits at the entry, and finds
+# the first one's end event when it gets in; (2) a patched forward issued while another one is still in flight on a
+# different stream is ORDERED behind it (the stream waits for the other forward's end event; said once in a warning)
+# instead of hanging the device: two streams then buy no overlap, and nothing deadlocks.  TOME_ONE_FORWARD=raise
+# refuses instead.
 _in_flight = {}  # device index -> (stream id, event recorded behind the last patched forward)
+_issue_locks: Dict[int, "threading.RLock"] = {}
+_issue_locks_guard = threading.Lock()
 _warned_two_streams = False
 
 
-def _guard_one_forward_in_flight(device) -> None:
-    global _warned_two_streams
-    if device.type != "cuda" or torch.cuda.is_current_stream_capturing():
-        return  # (a captured forward is ordered by the graph it is replayed from)
+def _current_stream(device):
+    """(stream id, stream) of the caller's current HIP stream -- a seam for the CPU-side test of the bookkeeping."""
     cur = torch.cuda.current_stream(device)
+    return cur.cuda_stream, cur
+
+
+def _record_event(stream):
+    ev = torch.cuda.Event()
+    ev.record(stream)
+    return ev
+
+
+def _guarded(device) -> bool:
+    return device.type == "cuda" and not torch.cuda.is_current_stream_capturing()
+    # (a captured forward is ordered by the graph it is replayed from)
+
+
+def _issue_lock(device):
+    with _issue_locks_guard:
+        lock = _issue_locks.get(device.index)
+        if lock is None:
+            lock = _issue_locks[device.index] = threading.RLock()
+        return lock
+
+
+def _guard_one_forward_in_flight(device) -> None:
+    """Called at the ENTRY of a patched forward, with the device's issue lock held."""
+    global _warned_two_streams
+    sid, cur = _current_stream(device)
     last = _in_flight.get(device.index)
-    if last is None or last[0] == cur.cuda_stream or last[1].query():
+    if last is None or last[0] == sid or last[1].query():
         return
     msg = ("a forward issued on another HIP stream of this process is still in flight: the library GEMMs of two "
-           "concurrent forwards (hipBLASLt Stream-K, persistent grids) deadlock on this platform")
+           "concurrent forwards never finish on this platform")
     if os.environ.get("TOME_ONE_FORWARD", "order") == "raise":
         raise RuntimeError(msg + ".  Run one forward at a time per process (one process per GPU).")
     cur.wait_event(last[1])
@@ -94,12 +124,38 @@ def _guard_one_forward_in_flight(device) -> None:
 
 
 def _note_forward_issued(device) -> None:
-    if device.type != "cuda" or torch.cuda.is_current_stream_capturing():
-        return
-    cur = torch.cuda.current_stream(device)
-    ev = torch.cuda.Event()
-    ev.record(cur)
-    _in_flight[device.index] = (cur.cuda_stream, ev)
+    sid, cur = _current_stream(device)
+    _in_flight[device.index] = (sid, _record_event(cur))
+
+
+class one_forward_at_a_time:
+    """Context of one patched forward on `device`: takes the device's issue lock (re-entrant: a patched model called
+    from inside another patched forward of the same thread), orders the caller's stream behind a forward still in
+    flight on another stream, and records the end event on exit -- also when the forward raises, since whatever it
+    enqueued before raising is in flight all the same."""
+
+    def __init__(self, device):
+        self.device = device
+        self.on = device is not None and _guarded(device)
+
+    def __enter__(self):
+        if self.on:
+            self.lock = _issue_lock(self.device)
+            self.lock.acquire()
+            try:
+                _guard_one_forward_in_flight(self.device)
+            except BaseException:
+                self.lock.release()
+                raise
+        return self
+
+    def __exit__(self, *exc):
+        if self.on:
+            try:
+                _note_forward_issued(self.device)
+            finally:
+                self.lock.release()
+        return False
 
 
 def wrap_model_forward(model_wrapper: torch.nn.Module, blocks_of: Callable) -> None:
@@ -110,18 +166,15 @@ def wrap_model_forward(model_wrapper: torch.nn.Module, blocks_of: Callable) -> N
         return
 
     def forward(self, *args, **kwdargs):
-        self._tome_info["r"] = parse_r(len(blocks_of(self)), self.r)
-        self._tome_info["size"] = None
-        self._tome_info["source"] = None
-        self._tome_info.pop("_prenorm", None)
-        self._tome_info.pop("_folded", None)
         param = next(self.parameters(), None)
-        if param is not None:
-            _guard_one_forward_in_flight(param.device)
-        out = super(sub, self).forward(*args, **kwdargs)
-        if param is not None:
-            _note_forward_issued(param.device)
-        return out
+        with one_forward_at_a_time(None if param is None else param.device):
+            # (the shared state is reset under the lock: `_tome_info` belongs to the forward that holds it)
+            self._tome_info["r"] = parse_r(len(blocks_of(self)), self.r)
+            self._tome_info["size"] = None
+            self._tome_info["source"] = None
+            self._tome_info.pop("_prenorm", None)
+            self._tome_info.pop("_folded", None)
+            return super(sub, self).forward(*args, **kwdargs)
 
     sub = type("ToMeVisionTransformer", (base,), {"forward": forward, "_tome_tag": "ToMeVisionTransformer"})
     model_wrapper.__class__ = sub
