@@ -6,10 +6,11 @@ LayerNorm / GELU passes of one half under the MFMA-bound GEMMs and attention of 
 
 Result on this pool (round 2): two forwards in flight on two streams of one process never finish -- also with
 r=0 and every TOME_* kernel switched off (TOME_ATTN_KERNEL=0 TOME_FUSE_NEXT=0 TOME_GELU_KERNEL=0), i.e. with the
-framework's kernels alone; each replica alone on its side stream is fine.  Round 3 found the cause: every GEMM of the
-model runs as hipBLASLt's persistent Stream-K kernel (`..._SK3_..._MT256x256x64`, one workgroup per CU spinning on its
-siblings' partial tiles), and two such grids resident at once deadlock -- tools/probes/two_stream_gemm.py reproduces it
-with two chains of plain torch.mm (88 ms on one stream; not finished after 20 s on two).  Since then a patched forward
+framework's kernels alone; each replica alone on its side stream is fine.  Round 3 reduced it to two chains of plain
+torch.mm (tools/probes/two_stream_gemm.py: 88 ms on one stream; not finished after 20 s on two).  Every GEMM of the
+model runs as a persistent Stream-K kernel (`..._SK3_..._MT256x256x64`, one workgroup per CU spinning on its siblings'
+partial tiles) under either BLAS preference (profiles/r04_two_stream_probe_rocblas_kernel.txt), so two such grids
+waiting on each other is the likely cause; the probe has no non-Stream-K control.  Since then a patched forward
 issued while another is in flight on a different stream is ORDERED behind it (tome/patch/_common.py,
 `_guard_one_forward_in_flight`): this script now finishes, and shows that two streams buy nothing.  The script still
 gives up after 40 s instead of hanging, with the host stack dumped at 30 s.

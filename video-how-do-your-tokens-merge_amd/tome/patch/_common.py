@@ -64,8 +64,11 @@ def new_tome_info(trace_source, prop_attn, mode, head_aggregation, threshold, ve
 # One forward in flight per process.  Two forwards (patched or not) issued on two HIP streams of one process never
 # finish on this platform: two chains of plain library GEMMs (`torch.mm`, nothing of this package) on two streams are
 # not finished after 20 s where one stream takes 88 ms (tools/probes/two_stream_gemm.py,
-# profiles/r03_two_stream_gemm_probe.txt) -- with either BLAS preference, so the cause is "two concurrent library GEMM
-# grids", not one particular kernel (see the probe's docstring for what the kernel trace of the finishing leg shows).
+# profiles/r03_two_stream_gemm_probe.txt).  Every GEMM of these models -- under either BLAS preference, as the kernel
+# trace in profiles/r04_two_stream_probe_rocblas_kernel.txt shows -- is a persistent Stream-K grid (`..._SK3_...`, one
+# workgroup per CU, workgroups spin on each other's partial tiles); two such grids resident at once waiting on
+# siblings that cannot be scheduled is the likely cause, but the probe has no non-Stream-K control, so the rule below
+# is stated for "two concurrent library GEMM grids".
 # The reference's own contract is one forward at a time per model (`_tome_info` is shared state, SURVEY 8b
 # "Threading").  So: (1) the ENQUEUEING of a patched forward holds a per-device lock -- a second host thread that
 # starts a forward while the first is still issuing kernels (launches release the GIL) waits at the entry, and finds
