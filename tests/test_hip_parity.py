@@ -126,6 +126,12 @@ def _filter_metric(kind, n, T, D, seed):
     elif kind == "scales":             # norms spread over 2^-40 .. 2^40: the reciprocal scaling is exercised
         m = synth.normal_like((n, T, D), seed)
         m *= np.exp2(g.integers(-40, 41, size=(n, T, 1))).astype(np.float32)
+    elif kind == "denormal_products":  # norms 2^-70 .. 2^-40 around FILT_NORM_LO = 1e-14: the products v_i[k] v_j[k] of two
+        m = synth.normal_like((n, T, D), seed)   # such tokens are denormal (flushed inside the bf16 matrix instruction)
+        m *= np.exp2(g.integers(-70, -39, size=(n, T, 1))).astype(np.float32)
+    elif kind == "large_norms":        # norms 2^50 .. 2^62 around FILT_NORM_HI = 1e18 (and a squared norm that overflows)
+        m = synth.normal_like((n, T, D), seed)
+        m *= np.exp2(g.integers(50, 63, size=(n, T, 1))).astype(np.float32)
     else:
         raise ValueError(kind)
     return torch.from_numpy(np.ascontiguousarray(m)).to(torch.bfloat16)
@@ -137,7 +143,8 @@ def _same_plan(a, b, what):
     assert torch.equal(a.node_max.view(torch.int32), b.node_max.view(torch.int32)), f"{what}: node_max bits"
 
 
-@pytest.mark.parametrize("kind", ["normal", "clustered", "duplicates", "ramp", "nan", "tiny", "huge", "scales"])
+@pytest.mark.parametrize("kind", ["normal", "clustered", "duplicates", "ramp", "nan", "tiny", "huge", "scales",
+                                  "denormal_products", "large_norms"])
 @pytest.mark.parametrize("n,T,D", [(3, 197, 64), (2, 784, 64), (1, 1568, 64), (4, 65, 16), (2, 3, 8), (2, 64, 64),
                                    (1, 3137, 64), (5, 130, 40)])
 def test_match_candidate_filter_is_bit_identical_to_the_fp32_pass(kind, n, T, D, monkeypatch):
@@ -146,8 +153,10 @@ def test_match_candidate_filter_is_bit_identical_to_the_fp32_pass(kind, n, T, D,
     small launches too) against the same call with the filter off (k_scores_rowmax on every tile) and against the
     oracle on the rounded values: src / dst / unm indices and the BITS of node_max, with and without a class token /
     a protected column, for r in {5, 16, all}.  The kinds cover the filter's every exit: one candidate per row, near-ties
-    inside the window, exact ties and monotone columns (list overflow -> fp32 pass of that tile), NaN / zero / inf tokens,
-    norms outside the trusted range (whole matching on the fp32 pass), norms spread over 80 binades."""
+    inside the window, exact ties and monotone columns (list overflow -> fp32 pass of that tile, run by a wave of the
+    k_exact_rows launch), NaN / zero / inf tokens, norms outside the trusted range [1e-14, 1e18] (the tiles concerned on
+    the fp32 pass: a row's own tile, every tile of a group for a column), norms spread over 80 binades, norms so small
+    that products of two tokens' channels are denormal."""
     from tome import _abi
     metric = _filter_metric(kind, n, T, D, 1234 + 13 * T + D).to(DEV)
     host = metric.float().cpu().numpy()
@@ -163,7 +172,7 @@ def test_match_candidate_filter_is_bit_identical_to_the_fp32_pass(kind, n, T, D,
         # (oracle comparison: not for NaN tokens -- that rule is pinned by test_nan_rule... -- and not for "tiny": a
         # token whose squared norm underflows has +-inf unit channels, its scores are NaN without its unit vector
         # being NaN, a case outside the NaN-flag contract of both paths alike)
-        if kind not in ("nan", "tiny"):
+        if kind not in ("nan", "tiny", "large_norms"):  # (large_norms: some squared norms overflow -> norm inf, as "huge")
             plan = oracle.match(host, r, cls, dist)
             np.testing.assert_array_equal(got.src_idx.cpu().numpy(), plan.src_idx)
             np.testing.assert_array_equal(got.dst_idx.cpu().numpy(), plan.dst_idx)

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Randomised campaign: the candidate-filter path of the matching (csrc/tome_match_filter.h) against the fp32 pass, on
 bf16 keys -- indices and node_max bits must be identical.  Shapes, key statistics (plain normal, per-token scales,
-low-rank structure that packs cosines close together, duplicated tokens) and r are drawn at random.
+low-rank structure that packs cosines close together, duplicated tokens, norms at both ends of the filter's trusted
+range) and r are drawn at random.
     python tools/filter_fuzz.py [cases] [seed]"""
 import os
 import sys
@@ -26,7 +27,7 @@ for c in range(cases):
     n = max(1, min(ri(1, 24), 40000 // T))
     heads = ri(0, 1) == 1
     D = 64 if heads else [8, 16, 24, 40, 64][ri(0, 4)]
-    kind = ri(0, 4)
+    kind = ri(0, 6)
     shape = (n, T, 12, 64) if heads else (n, T, D)
     x = torch.randn(shape, device=dev, generator=g)
     if kind == 1:      # per-token scales over many binades
@@ -41,6 +42,10 @@ for c in range(cases):
         x = x[:, : max(1, (T + rep - 1) // rep)].repeat_interleave(rep, dim=1)[:, :T]
     elif kind == 4:    # nearly constant token + tiny differences (all cosines within 1e-4 of 1)
         x = x[:, :1] + 10.0 ** (-ri(2, 3)) * x
+    elif kind == 5:    # norms 2^-70 .. 2^-40: products of two tokens' channels are denormal (FILT_NORM_LO = 1e-14)
+        x = x * torch.exp2(torch.randint(-70, -39, shape[:2] + (1,) * (len(shape) - 2), device=dev, generator=g).float())
+    elif kind == 6:    # norms 2^40 .. 2^62 around FILT_NORM_HI = 1e18, squared norms up to overflow
+        x = x * torch.exp2(torch.randint(40, 63, shape[:2] + (1,) * (len(shape) - 2), device=dev, generator=g).float())
     x = x.bfloat16()
     r = [1, 5, 16, 32, T][ri(0, 4)]
     cls, dist = ri(0, 3) == 0, ri(0, 7) == 0

@@ -254,31 +254,27 @@ static int match_tail(const MatchWs &w, int64_t n, int64_t T, int64_t D, int64_t
             hipLaunchKernelGGL(k_scores_filter, dim3((unsigned)(((n + 7) / 8) * 8 * ((w.ntA + FILT_ATW - 1) / FILT_ATW))),
                                dim3(64), sizeof(float) * (size_t)w.T2p, st, w.vA, w.vB,
                                w.normA, w.invB, (int)n, T1, T2, w.T2p, w.ntA, w.ntB, distill_token, w.cand, w.cand_n,
-                               w.tile_flag, w.any_flag);
+                               w.tile_flag);
             if (int rc = check_launch("k_scores_filter")) return rc;
-            // 2b. tiles whose candidate lists overflowed take the fp32 pass: unit vectors, then k_scores_rowmax on
-            // the flagged tiles only (both return at once when nothing is flagged)
-            hipLaunchKernelGGL(k_units_from_means, dim3(1024), dim3(256), 0, st, w.vA, w.vB, w.normA, w.normB, (int)n,
-                               (int)T, w.ntA, w.ntB, w.unitA, w.unitB, w.groupA_f4, w.groupB_f4, w.any_flag);
-            if (int rc = check_launch("k_units_from_means")) return rc;
+            // 2b. the exact score of every row's winner; the same launch carries one wave per A tile that takes the
+            // fp32 pass when the filter flagged the tile (overflowed candidate list, norm out of range) and leaves at
+            // once otherwise
+            const int64_t exact_blocks = (n * T1 + 255) / 256, fb_blocks = (n * w.ntA + 3) / 4;
+            hipLaunchKernelGGL(k_exact_rows, dim3((unsigned)(exact_blocks + fb_blocks)), dim3(256), 0, st, w.vA, w.vB,
+                               w.normA, w.normB, (int)n, T1, T2, (int)D, w.ntA, w.ntB, w.cand, w.cand_n, w.tile_flag,
+                               (int)exact_blocks, distill_token, w.node_max, w.node_idx);
+            if (int rc = check_launch("k_exact_rows")) return rc;
+            continue;
         }
-        const uint8_t *tflag = filtered ? w.tile_flag : nullptr;
         if (w.nchunk == 1)
             hipLaunchKernelGGL(k_scores_rowmax<true>, dim3(nb2), dim3(64), 0, st, (const f32x4 *)w.unitA,
                                (const f32x4 *)w.unitB, (int)n, T1, T2, w.nchunk, w.ntA, w.ntB, WJ, w.groupA_f4,
-                               w.groupB_f4, distill_token, w.part_max, w.part_idx, tflag);
+                               w.groupB_f4, distill_token, w.part_max, w.part_idx, nullptr);
         else
             hipLaunchKernelGGL(k_scores_rowmax<false>, dim3(nb2), dim3(64), 0, st, (const f32x4 *)w.unitA,
                                (const f32x4 *)w.unitB, (int)n, T1, T2, w.nchunk, w.ntA, w.ntB, WJ, w.groupA_f4,
-                               w.groupB_f4, distill_token, w.part_max, w.part_idx, tflag);
+                               w.groupB_f4, distill_token, w.part_max, w.part_idx, nullptr);
         if (int rc = check_launch("k_scores_rowmax")) return rc;
-        if (filtered) {
-            // 2c. the exact score of every row's winner
-            hipLaunchKernelGGL(k_exact_rows, dim3((unsigned)((n * T1 + 255) / 256)), dim3(256), 0, st, w.vA, w.vB,
-                               w.normA, w.normB, (int)n, T1, T2, (int)D, w.ntA, w.ntB, w.cand, w.cand_n, w.tile_flag,
-                               w.part_max, w.part_idx, WJ, distill_token, w.node_max, w.node_idx);
-            if (int rc = check_launch("k_exact_rows")) return rc;
-        }
     }
     prof_mark(2, st);
 
@@ -323,10 +319,9 @@ extern "C" int tome_match(const void *metric, int dtype, int64_t n, int64_t T, i
     for (int rep = 0; rep < prof_reps; ++rep) {
     launched = false;
     if (filtered) {
-        (void)hipMemsetAsync(w.any_flag, 0, sizeof(int), st);
         hipLaunchKernelGGL(k_unit_rows_f<false>, dim3((unsigned)((n * T + 31) / 32)), dim3(256), 0, st,
                            (const bf16_t *)metric, stride_n, 1, (int64_t)0, (int64_t)0, stride_t, (int)n, 1, (int)T, (int)D,
-                           w.vA, w.vB, w.ntA, w.ntB, w.normA, w.normB, w.invB, w.T2p, w.badA, w.badB, w.any_flag);
+                           w.vA, w.vB, w.ntA, w.ntB, w.normA, w.normB, w.invB, w.T2p, w.badA, w.badB);
         continue;
     }
 #define UNIT_FAST(TY, NCH)                                                                                    \
@@ -407,10 +402,9 @@ extern "C" int tome_match_keys(const void *keys, int dtype, int64_t n, int64_t H
     const bool filtered = use_filter(w, dtype, n, D);
     for (int rep = 0; rep < prof_reps; ++rep) {
         if (filtered) {
-            (void)hipMemsetAsync(w.any_flag, 0, sizeof(int), st);
             hipLaunchKernelGGL(k_unit_rows_f<true>, dim3(nb), dim3(256), 0, st, (const bf16_t *)keys, stride_n, (int)inner,
                                stride_inner, stride_h, stride_t, (int)n, (int)H, (int)T, (int)D, w.vA, w.vB, w.ntA, w.ntB,
-                               w.normA, w.normB, w.invB, w.T2p, w.badA, w.badB, w.any_flag);
+                               w.normA, w.normB, w.invB, w.T2p, w.badA, w.badB);
             continue;
         }
         switch (dtype) {
@@ -510,7 +504,27 @@ static int launch_merge_rows(const void *x, const void *size, int64_t n, int64_t
         const int64_t ny = n + (cls_rows ? (cls_rows + 4 * bpg - 1) / (4 * bpg) : 0);
         const int64_t gy = ny < 65535 ? ny : 65535, gz = (ny + gy - 1) / gy;
         if (gz > 65535) return fail(TOME_EINVAL, "merge: too many groups (%lld)", (long long)n);
-        const dim3 grid((unsigned)bpg, (unsigned)gy, (unsigned)gz);
+        dim3 grid((unsigned)bpg, (unsigned)gy, (unsigned)gz);
+        // XCD-aware numbering of the workgroups (MergeSched, csrc/tome_merge.h) when the launch has several blocks per
+        // group and fits a 1-D grid; TOME_MERGE_XCD=0 keeps the (blocks, group) grid (measurement switch, read per call)
+        MergeSched sch{(unsigned)bpg, (unsigned)(bpg * ny), 0u, 0, 0ull};
+        {
+            const char *xe = getenv("TOME_MERGE_XCD");
+            const int64_t total = bpg * ny;
+            if (!(xe && xe[0] == '0') && total < (1ll << 28) && bpg < (1ll << 12) && total >= 64) {
+                sch.per_xcd = (unsigned)((total + 7) / 8);
+                sch.on = 1;
+                sch.magic = ((1ull << 40) + (unsigned long long)bpg - 1ull) / (unsigned long long)bpg;
+                grid = dim3(8u * sch.per_xcd, 1u, 1u);
+            }
+        }
+#ifdef TOME_OCC_PROBE
+        const char *lds_e = getenv("TOME_MERGE_LDS");
+        const unsigned occ_lds = lds_e ? (unsigned)atoi(lds_e) : 0u;
+#define OCC_LDS occ_lds
+#else
+#define OCC_LDS 0
+#endif
         if (ln_p) {
             if (OP != OP_WAVG || sizeof(TX) != 2 || cpr > 2 * WAVE || !aligned16(ln_p->y) || !aligned16(ln_p->weight) ||
                 !aligned16(ln_p->bias))
@@ -521,30 +535,30 @@ static int launch_merge_rows(const void *x, const void *size, int64_t n, int64_t
                 const char *ee = getenv("TOME_MERGE_EAGER");
                 const bool eager = r <= 64 && ((ee && ee[0] == '1') || (!(ee && ee[0] == '0') && 8 * r >= T));
                 if (eager && nit == 3)
-                    hipLaunchKernelGGL((k_merge_rows_fast<TX, TS, OP, 3, true, true>), grid, dim3(256), 0, st, (const TX *)x,
+                    hipLaunchKernelGGL((k_merge_rows_fast<TX, TS, OP, 3, true, true>), grid, dim3(256), OCC_LDS, st, (const TX *)x,
                                        (const TS *)size, (int)n, (int)T, (int)C, (int)r, R, (int)cpr, (int)((To + R - 1) / R), src, dst, unm,
-                                       distill, keep, (TX *)xout, (TS *)sout, lin, lout, cls_rows, *ln_p, (TS *)lsout);
+                                       distill, keep, (TX *)xout, (TS *)sout, lin, lout, cls_rows, *ln_p, (TS *)lsout, sch);
                 else if (eager)
-                    hipLaunchKernelGGL((k_merge_rows_fast<TX, TS, OP, 6, true, true>), grid, dim3(256), 0, st, (const TX *)x,
+                    hipLaunchKernelGGL((k_merge_rows_fast<TX, TS, OP, 6, true, true>), grid, dim3(256), OCC_LDS, st, (const TX *)x,
                                        (const TS *)size, (int)n, (int)T, (int)C, (int)r, R, (int)cpr, (int)((To + R - 1) / R), src, dst, unm,
-                                       distill, keep, (TX *)xout, (TS *)sout, lin, lout, cls_rows, *ln_p, (TS *)lsout);
+                                       distill, keep, (TX *)xout, (TS *)sout, lin, lout, cls_rows, *ln_p, (TS *)lsout, sch);
                 else if (nit == 3)
-                    hipLaunchKernelGGL((k_merge_rows_fast<TX, TS, OP, 3, true>), grid, dim3(256), 0, st, (const TX *)x,
+                    hipLaunchKernelGGL((k_merge_rows_fast<TX, TS, OP, 3, true>), grid, dim3(256), OCC_LDS, st, (const TX *)x,
                                        (const TS *)size, (int)n, (int)T, (int)C, (int)r, R, (int)cpr, (int)((To + R - 1) / R), src, dst, unm,
-                                       distill, keep, (TX *)xout, (TS *)sout, lin, lout, cls_rows, *ln_p, (TS *)lsout);
+                                       distill, keep, (TX *)xout, (TS *)sout, lin, lout, cls_rows, *ln_p, (TS *)lsout, sch);
                 else
-                    hipLaunchKernelGGL((k_merge_rows_fast<TX, TS, OP, 6, true>), grid, dim3(256), 0, st, (const TX *)x,
+                    hipLaunchKernelGGL((k_merge_rows_fast<TX, TS, OP, 6, true>), grid, dim3(256), OCC_LDS, st, (const TX *)x,
                                        (const TS *)size, (int)n, (int)T, (int)C, (int)r, R, (int)cpr, (int)((To + R - 1) / R), src, dst, unm,
-                                       distill, keep, (TX *)xout, (TS *)sout, lin, lout, cls_rows, *ln_p, (TS *)lsout);
+                                       distill, keep, (TX *)xout, (TS *)sout, lin, lout, cls_rows, *ln_p, (TS *)lsout, sch);
             }
         } else if (nit == 3)
-            hipLaunchKernelGGL((k_merge_rows_fast<TX, TS, OP, 3>), grid, dim3(256), 0, st, (const TX *)x,
+            hipLaunchKernelGGL((k_merge_rows_fast<TX, TS, OP, 3>), grid, dim3(256), OCC_LDS, st, (const TX *)x,
                                (const TS *)size, (int)n, (int)T, (int)C, (int)r, R, (int)cpr, (int)((To + R - 1) / R), src, dst, unm, distill,
-                               keep, (TX *)xout, (TS *)sout, lin, lout, cls_rows, no_ln, (TS *)lsout);
+                               keep, (TX *)xout, (TS *)sout, lin, lout, cls_rows, no_ln, (TS *)lsout, sch);
         else
-            hipLaunchKernelGGL((k_merge_rows_fast<TX, TS, OP, 6>), grid, dim3(256), 0, st, (const TX *)x,
+            hipLaunchKernelGGL((k_merge_rows_fast<TX, TS, OP, 6>), grid, dim3(256), OCC_LDS, st, (const TX *)x,
                                (const TS *)size, (int)n, (int)T, (int)C, (int)r, R, (int)cpr, (int)((To + R - 1) / R), src, dst, unm, distill,
-                               keep, (TX *)xout, (TS *)sout, lin, lout, cls_rows, no_ln, (TS *)lsout);
+                               keep, (TX *)xout, (TS *)sout, lin, lout, cls_rows, no_ln, (TS *)lsout, sch);
         return check_launch("k_merge_rows_fast");
     }
     if (cls_rows || ln_p)

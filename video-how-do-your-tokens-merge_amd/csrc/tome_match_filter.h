@@ -17,8 +17,12 @@
 //      (normally one, two for near-ties) are evaluated with the contract's own arithmetic (fdiv + fma chain in k
 //      order); the largest exact score wins, the smallest column among equals -- the same bits k_scores_rowmax gives.
 //   3. A lane whose list overflows (tie-heavy or monotone data: more than FILT_KH near-records in its half row) flags
-//      its tile; flagged tiles are recomputed by k_scores_rowmax itself (k_units_from_means builds their fp32 unit
-//      vectors first) -- the filter degrades to the full fp32 pass, never to a different answer.
+//      its tile, and so does a norm outside [FILT_NORM_LO, FILT_NORM_HI]; a flagged tile is recomputed on the fp32
+//      matrix pipe with k_scores_rowmax's arithmetic by a wave of the k_exact_rows launch (fp32_pass_of_tile) -- the
+//      filter degrades to the full fp32 pass, never to a different answer.
+//   Launches of one matching on this path: k_unit_rows_f, k_scores_filter, k_exact_rows (+ its fallback waves),
+//   k_rank_select -- four, none of them idle, no flag word to clear (round 4; rounds 2-3 ran seven: a memset, two
+//   fallback kernels that returned at once, and k_scores_rowmax on the flagged tiles).
 //
 // Error bound.  v are bf16 (8 significant bits): every product v_i[k] v_j[k] is exact in fp32.  With D <= 64 terms the
 // bf16 MFMA's fp32 accumulation differs from the exact dot product by <= 64 * 2^-24 * sum|v_i[k] v_j[k]| <= 3.9e-6
@@ -30,6 +34,11 @@
 
 #define FILT_KH 4            // records per lane (= per half row): (B tile, 16-bit mask of its columns) pairs
 #define FILT_WINDOW 4e-5f
+// Norms the bound above holds for.  Below LO the products v_i[k] v_j[k] of two such tokens reach the denormal range
+// (flushed inside the matrix instruction: 64 flushed terms of < 2^-126 against ||v_i|| ||v_j|| >= 1e-28 stay below 1e-8
+// of the cosine; with 1e-30, round 3's bound, they did not); above HI a dot product of two such tokens may overflow.
+#define FILT_NORM_LO 1e-14f
+#define FILT_NORM_HI 1e18f
 
 typedef __bf16 filt_bf16x8 __attribute__((ext_vector_type(8)));
 
@@ -54,8 +63,7 @@ __global__ __launch_bounds__(256) void k_unit_rows_f(const bf16_t *__restrict__ 
                                                      uint4 *__restrict__ vB, int ntA, int ntB,
                                                      float *__restrict__ normA, float *__restrict__ normB,
                                                      float *__restrict__ invB, int T2p, uint8_t *__restrict__ badA,
-                                                     uint8_t *__restrict__ badB, int *__restrict__ any_flag) {
-    // (any_flag is cleared by a memset node in front of this launch: other blocks may set bit 1 before block 0 runs)
+                                                     uint8_t *__restrict__ badB) {
     const int lane = threadIdx.x & 63;
     const int b8 = lane & 7;
     const int64_t tok = ((int64_t)blockIdx.x * (blockDim.x >> 3)) + (threadIdx.x >> 3);
@@ -126,9 +134,9 @@ __global__ __launch_bounds__(256) void k_unit_rows_f(const bf16_t *__restrict__ 
     const unsigned long long nan_mask = __ballot(nan_here);
     if (live && b8 == 0) {
         const uint8_t flag = ((nan_mask >> (lane & ~7)) & 0xFFull) ? 1 : 0;
-        // a usable token whose norm is so small or large that 1/||v|| (or its products) may leave the finite range:
-        // the approximate scores cannot be trusted -- the whole matching takes the fp32 pass (never seen on real keys)
-        if (!flag && !(nr >= 1e-30f && nr <= 1e30f)) atomicOr(any_flag, 2);
+        // (a usable token whose norm is so small or large that 1/||v|| or its products may leave the normal fp32 range:
+        // k_scores_filter reads the norms it works with and sends the tiles concerned to the fp32 pass itself --
+        // FILT_NORM_LO / FILT_NORM_HI there; nothing is flagged here, so no flag word needs clearing before this launch)
         if (odd) {
             badB[(int64_t)g * (T_ >> 1) + rowi] = flag;
             normB[(int64_t)g * (T_ >> 1) + rowi] = nr;
@@ -159,8 +167,7 @@ __global__ __launch_bounds__(64) void k_scores_filter(const uint4 *__restrict__ 
                                                       const float *__restrict__ normA, const float *__restrict__ invB,
                                                       int n, int T1, int T2, int T2p, int ntA, int ntB,
                                                       int distill_token, CandEntry *__restrict__ cand,
-                                                      uint8_t *__restrict__ cand_n, uint8_t *__restrict__ tile_flag,
-                                                      int *__restrict__ any_flag) {
+                                                      uint8_t *__restrict__ cand_n, uint8_t *__restrict__ tile_flag) {
     extern __shared__ __attribute__((aligned(16))) float s_inv[];  // [T2p]
     const int L = blockIdx.x;
     const int xcd = L & 7, qq = L >> 3;
@@ -171,7 +178,20 @@ __global__ __launch_bounds__(64) void k_scores_filter(const uint4 *__restrict__ 
     const int lane = threadIdx.x;
     const int col = lane & 31, h = lane >> 5;
 
-    for (int j = lane; j < T2p; j += 64) s_inv[j] = invB[(int64_t)g * T2p + j];
+    // Norms the approximate scores cannot be trusted with: a usable token whose norm lies outside
+    // [FILT_NORM_LO, FILT_NORM_HI] -- its reciprocal, or a product v_i[k] * v_j[k] / (||v_i|| ||v_j||) of two such tokens,
+    // may leave the NORMAL fp32 range (denormals are flushed inside the bf16 matrix instruction), and then the error
+    // bound of the header does not hold.  A column like that sends every tile of its group to the fp32 pass, a row like
+    // that its own tile (never seen on real keys).  Decided here from the norms this wave reads anyway, per tile, with
+    // plain stores: no flag word that would have to be cleared in front of the matching.
+    bool b_out = false;
+    for (int j = lane; j < T2p; j += 64) {
+        const float iv = invB[(int64_t)g * T2p + j];
+        s_inv[j] = iv;
+        // (NaN = a token whose unit vector holds a NaN: handled by the NaN rule, not a range problem)
+        b_out = b_out || (j < T2 && iv == iv && !(iv >= 1.0001f / FILT_NORM_HI && iv <= 0.9999f / FILT_NORM_LO));
+    }
+    const bool force_group = __ballot(b_out) != 0ull;
     __syncthreads();  // (one wave: orders the LDS writes in front of the other lanes' reads)
 
     filt_bf16x8 a[FILT_ATW][4];
@@ -182,7 +202,7 @@ __global__ __launch_bounds__(64) void k_scores_filter(const uint4 *__restrict__ 
     float window[FILT_ATW], thr[FILT_ATW];
     int cnt[FILT_ATW];
     unsigned rec[FILT_ATW][FILT_KH];
-    bool row_ok[FILT_ATW];
+    bool row_ok[FILT_ATW], a_out[FILT_ATW];
 #pragma unroll
     for (int u = 0; u < FILT_ATW; ++u) {
         const int ti = min(ti0 + u, ntA - 1);  // (a wave past the last tile repeats it and writes nothing)
@@ -195,7 +215,9 @@ __global__ __launch_bounds__(64) void k_scores_filter(const uint4 *__restrict__ 
         const int i = ti * TILE_ROWS + col;
         row_ok[u] = (ti0 + u < ntA) && i < T1;
         // the window on the scale of S~ = S * ||v_i||
-        window[u] = FILT_WINDOW * (row_ok[u] ? normA[(int64_t)g * T1 + i] : 0.0f);
+        const float ni = row_ok[u] ? normA[(int64_t)g * T1 + i] : 1.0f;
+        a_out[u] = !(ni >= FILT_NORM_LO && ni <= FILT_NORM_HI);
+        window[u] = FILT_WINDOW * (row_ok[u] ? ni : 0.0f);
         thr[u] = -INFINITY;
         cnt[u] = 0;
 #pragma unroll
@@ -263,9 +285,6 @@ __global__ __launch_bounds__(64) void k_scores_filter(const uint4 *__restrict__ 
             cnt[u] += hitlane ? 1 : 0;
         }
     }
-    bool force = false;
-    if (lane == 0) force = (*any_flag & 2) != 0;
-    force = __shfl(force ? 1 : 0, 0) != 0;
 #pragma unroll
     for (int u = 0; u < FILT_ATW; ++u) {
         const int ti = ti0 + u;
@@ -277,87 +296,124 @@ __global__ __launch_bounds__(64) void k_scores_filter(const uint4 *__restrict__ 
             uint4 out = uint4{rec[u][0], rec[u][1], rec[u][2], rec[u][3]};
             *reinterpret_cast<uint4 *>(cand + slot * FILT_KH) = out;
         }
-        const unsigned long long ov = __ballot(row_ok[u] && cnt[u] > FILT_KH);
-        if (lane == 0) {
-            // (bit 1 of any_flag: a token with a norm outside 1e-30 .. 1e30 -- its reciprocal may not be finite:
-            // every tile takes the fp32 pass)
-            tile_flag[(int64_t)g * ntA + ti] = (ov || force) ? 1 : 0;
-            if (ov) atomicOr(any_flag, 1);
+        // a lane whose list overflowed (exact ties, monotone columns), or a norm out of range: the tile's rows get the
+        // fp32 pass (the fallback waves of the k_exact_rows launch)
+        const unsigned long long ov = __ballot(row_ok[u] && (cnt[u] > FILT_KH || a_out[u]));
+        if (lane == 0) tile_flag[(int64_t)g * ntA + ti] = (ov || force_group) ? 1 : 0;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// fp32 pass of ONE flagged A tile (32 rows), one wave, inside the k_exact_rows launch: the arithmetic of
+// k_scores_rowmax -- S^T tiles on v_mfma_f32_32x32x2_f32, k ascending (the contract's fma chain), first maximum -- over
+// ALL B tiles of the group, with the fp32 unit vectors u = fdiv(v, ||v||) made on the fly from the bf16 means and norms
+// (what k_unit_rows_heads would have written: same v, same norm, same correctly rounded division), in the fragment
+// order of that kernel: float4 q of lane (col, h) = channels 8q + h, 8q + 2 + h, 8q + 4 + h, 8q + 6 + h of row col.
+// Replaces the two launches (k_units_from_means + masked k_scores_rowmax) that ran -- idle -- behind every matching.
+// A flagged tile is rare (exact ties / duplicated tokens, norms out of range); when EVERY tile is flagged this sweep is
+// the whole similarity on the fp32 pipe with 32 divisions per lane and tile in front of 32 matrix instructions.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ f32x4 unit_quad(const uint4 &raw, int h, float nr) {
+    Pack<bf16_t, 8> pk;
+    __builtin_memcpy(&pk, &raw, 16);
+    f32x4 u;
+    u.x = __fdiv_rn(to_f32(h ? pk.e[1] : pk.e[0]), nr);
+    u.y = __fdiv_rn(to_f32(h ? pk.e[3] : pk.e[2]), nr);
+    u.z = __fdiv_rn(to_f32(h ? pk.e[5] : pk.e[4]), nr);
+    u.w = __fdiv_rn(to_f32(h ? pk.e[7] : pk.e[6]), nr);
+    return u;
+}
+
+__device__ __forceinline__ void fp32_pass_of_tile(const uint4 *__restrict__ vA, const uint4 *__restrict__ vB,
+                                                  const float *__restrict__ normA, const float *__restrict__ normB,
+                                                  int g, int ti, int T1, int T2, int ntA, int ntB, int distill_token,
+                                                  float *__restrict__ node_max, int *__restrict__ node_idx) {
+    const int lane = threadIdx.x & 63;
+    const int col = lane & 31, h = lane >> 5;
+    const int i = ti * TILE_ROWS + col;
+    f32x4 af[8];
+    {
+        const float ni = normA[(int64_t)g * T1 + (i < T1 ? i : T1 - 1)];
+        const uint4 *at = vA + ((int64_t)g * ntA + ti) * 256;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) af[q] = unit_quad(at[bfrag_index(0, q >> 1, col + 32 * (q & 1))], h, ni);
+    }
+    RowBest rb = {-INFINITY, 0};
+    uint4 braw[8];
+    float nj;
+    {
+        const uint4 *bt = vB + (int64_t)g * ntB * 256;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) braw[q] = bt[bfrag_index(0, q >> 1, col + 32 * (q & 1))];
+        nj = normB[(int64_t)g * T2 + (col < T2 ? col : T2 - 1)];
+    }
+    for (int jt = 0; jt < ntB; ++jt) {
+        uint4 cur[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) cur[q] = braw[q];
+        const float cn = nj;
+        {   // the next tile's means and norms (the last iteration re-reads its own)
+            const int nx = jt + 1 < ntB ? jt + 1 : jt;
+            const uint4 *bt = vB + ((int64_t)g * ntB + nx) * 256;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) braw[q] = bt[bfrag_index(0, q >> 1, col + 32 * (q & 1))];
+            const int jn = nx * TILE_ROWS + col;
+            nj = normB[(int64_t)g * T2 + (jn < T2 ? jn : T2 - 1)];
+        }
+        f32x16 acc;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) acc[v] = 0.0f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const f32x4 b = unit_quad(cur[q], h, cn), a = af[q];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.x, a.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.y, a.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.z, a.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.w, a.w, acc, 0, 0, 0);
+        }
+        fold_tile(acc, rb, jt, h, T2, distill_token);
+    }
+    {   // the two lane halves hold the same A row, disjoint B rows: keep the larger, first index on ties
+        const float ob = __shfl_xor(rb.best, 32);
+        const int oi = __shfl_xor(rb.idx, 32);
+        if (ob > rb.best || (ob == rb.best && oi < rb.idx)) {
+            rb.best = ob;
+            rb.idx = oi;
         }
     }
-}
-
-// ------------------------------------------------------------------------------------------------
-// k_units_from_means: the fp32 unit vectors (fragment-major tiles of k_scores_rowmax) from the bf16 means and norms
-// -- u = fdiv(v, ||v||), what k_unit_rows_heads writes.  Does nothing unless a tile was flagged.
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_units_from_means(const uint4 *__restrict__ vA, const uint4 *__restrict__ vB,
-                                                          const float *__restrict__ normA,
-                                                          const float *__restrict__ normB, int n, int T_, int ntA,
-                                                          int ntB, float *__restrict__ unitA, float *__restrict__ unitB,
-                                                          int64_t groupA_f4, int64_t groupB_f4,
-                                                          const int *__restrict__ any_flag) {
-    if (*any_flag == 0) return;
-    const int lane = threadIdx.x & 63;
-    const int b8 = lane & 7;
-    const int64_t ntok = (int64_t)n * T_;
-    for (int64_t tok = ((int64_t)blockIdx.x * (blockDim.x >> 3)) + (threadIdx.x >> 3); tok < ntok;
-         tok += (int64_t)gridDim.x * (blockDim.x >> 3)) {
-        const int g = (int)((uint32_t)tok / (uint32_t)T_);
-        const int t = (int)((uint32_t)tok - (uint32_t)g * (uint32_t)T_);
-        const int rowi = t >> 1;
-        const bool odd = t & 1;
-        const uint4 *src = odd ? vB + (int64_t)g * ntB * 256 : vA + (int64_t)g * ntA * 256;
-        const uint4 raw = src[bfrag_index(rowi >> 5, b8 >> 1, (rowi & 31) + 32 * (b8 & 1))];
-        Pack<bf16_t, 8> pk;
-        __builtin_memcpy(&pk, &raw, 16);
-        const float nr = odd ? normB[(int64_t)g * (T_ >> 1) + rowi] : normA[(int64_t)g * ((T_ + 1) >> 1) + rowi];
-        f32x4 ev, od;
-        ev.x = __fdiv_rn(to_f32(pk.e[0]), nr); od.x = __fdiv_rn(to_f32(pk.e[1]), nr);
-        ev.y = __fdiv_rn(to_f32(pk.e[2]), nr); od.y = __fdiv_rn(to_f32(pk.e[3]), nr);
-        ev.z = __fdiv_rn(to_f32(pk.e[4]), nr); od.z = __fdiv_rn(to_f32(pk.e[5]), nr);
-        ev.w = __fdiv_rn(to_f32(pk.e[6]), nr); od.w = __fdiv_rn(to_f32(pk.e[7]), nr);
-        f32x4 *dst = reinterpret_cast<f32x4 *>(odd ? unitB : unitA) + (int64_t)g * (odd ? groupB_f4 : groupA_f4);
-        const int64_t f = frag_index(rowi >> 5, 1, 0, b8, rowi & 31);
-        dst[f] = ev;
-        dst[f + 32] = od;
+    if (h == 0 && i < T1) {
+        node_max[(int64_t)g * T1 + i] = rb.best;
+        node_idx[(int64_t)g * T1 + i] = rb.idx;
     }
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_exact_rows: one lane per row.  Unflagged tile: the recorded columns within the window of the row's final
-// approximate maximum, each evaluated with the contract's arithmetic; flagged tile: the j-parts k_scores_rowmax has
-// written for it, folded in ascending order (strict >: the first maximum).  Output: node arrays [n][T1] in the layout
-// k_rank_select reads with nparts = 1.
+// k_exact_rows: blocks [0, exact_blocks): one lane per row of an UNFLAGGED tile -- the recorded columns within the
+// window of the row's final approximate maximum, each evaluated with the contract's arithmetic.  Blocks behind them:
+// four waves each, one flagged tile per wave on the fp32 matrix pipe (fp32_pass_of_tile; a wave whose tile is not
+// flagged leaves at once).  Output: node arrays [n][T1] in the layout k_rank_select reads with nparts = 1.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_exact_rows(const uint4 *__restrict__ vA, const uint4 *__restrict__ vB,
                                                     const float *__restrict__ normA, const float *__restrict__ normB,
                                                     int n, int T1, int T2, int D, int ntA, int ntB,
                                                     const CandEntry *__restrict__ cand,
                                                     const uint8_t *__restrict__ cand_n,
-                                                    const uint8_t *__restrict__ tile_flag,
-                                                    const float *__restrict__ part_max, const int *__restrict__ part_idx,
-                                                    int WJ, int distill_token, float *__restrict__ node_max,
+                                                    const uint8_t *__restrict__ tile_flag, int exact_blocks,
+                                                    int distill_token, float *__restrict__ node_max,
                                                     int *__restrict__ node_idx) {
+    if ((int)blockIdx.x >= exact_blocks) {
+        const int64_t tile = ((int64_t)blockIdx.x - exact_blocks) * 4 + (threadIdx.x >> 6);
+        if (tile >= (int64_t)n * ntA || !tile_flag[tile]) return;  // (wave-uniform)
+        const int gf = (int)(tile / ntA);
+        fp32_pass_of_tile(vA, vB, normA, normB, gf, (int)(tile - (int64_t)gf * ntA), T1, T2, ntA, ntB, distill_token,
+                          node_max, node_idx);
+        return;
+    }
     const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (row >= (int64_t)n * T1) return;
     const int g = (int)(row / T1), i = (int)(row - (int64_t)g * T1);
     const int ti = i >> 5;
-    if (tile_flag[(int64_t)g * ntA + ti]) {
-        float best = -INFINITY;
-        int bidx = 0;
-        for (int p = 0; p < WJ; ++p) {
-            const float pv = part_max[((int64_t)g * WJ + p) * T1 + i];
-            const int pj = part_idx[((int64_t)g * WJ + p) * T1 + i];
-            if (p == 0 || pv > best) {
-                best = pv;
-                bidx = pj;
-            }
-        }
-        node_max[row] = best;
-        node_idx[row] = bidx;
-        return;
-    }
+    if (tile_flag[(int64_t)g * ntA + ti]) return;  // (a fallback wave of this launch writes the tile's rows)
     // Everything the row needs from memory is requested in two rounds -- (counts, records, this row's bf16 mean), then
     // (the recorded columns' means and norms) -- instead of one dependent round trip per record and per column: the
     // first form of this kernel spent 48 us per sweep over the columns waiting for them one by one.

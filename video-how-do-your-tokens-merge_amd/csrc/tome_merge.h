@@ -262,6 +262,244 @@ __device__ __forceinline__ void ln_rows(const uint4 (&raw)[NIT], const int (&row
     }
 }
 
+// The tail of one destination row held by a whole wave as two 16-byte column chunks per lane (acc0 at column c0, acc1
+// at c1; a0 / a1 say which exist): division by the summed size (or the count, for "mean"), the stores of x' (with the
+// folded bias), size' (and its log), and the fused LayerNorm of the row as stored.  Shared by merge_dst_row and
+// merge_dst_row_r64, so both build bit-identical rows.
+// (pre: the lane's chunks of xbias / LayerNorm weight / bias when the caller has requested them ahead of its own
+// waits -- merge_dst_row_r64; nullptr: fetched here)
+template <typename TX, int VEC> struct RowConsts { Pack<TX, VEC> xb0, xb1, w0, w1, b0, b1; };
+
+template <typename TX, int VEC>
+__device__ __forceinline__ void unpack_f32(const Pack<TX, VEC> &p, float (&out)[VEC]) {
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) out[e] = to_f32(p.e[e]);
+}
+
+template <typename TX, typename TS, int VEC, int OP, bool LN, bool PRE = false>
+__device__ __forceinline__ void dst_row_finish(float (&acc0)[VEC], float (&acc1)[VEC], bool a0, bool a1, int c0, int c1,
+                                               float ssum, int cnt, int C, TX *__restrict__ orow, TS *__restrict__ srow,
+                                               TS *__restrict__ lrow, const LnArgs *ln, TX *__restrict__ yrow, int lane,
+                                               const RowConsts<TX, VEC> pre = RowConsts<TX, VEC>()) {
+    if (OP == OP_WAVG) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            if (a0) acc0[e] = __fdiv_rn(acc0[e], ssum);
+            if (a1) acc1[e] = __fdiv_rn(acc1[e], ssum);
+        }
+    } else if (OP == TOME_MEAN && cnt > 1) {
+        const float fc = (float)cnt;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            if (a0) acc0[e] = __fdiv_rn(acc0[e], fc);
+            if (a1) acc1[e] = __fdiv_rn(acc1[e], fc);
+        }
+    }
+    if (LN && ln->xbias) {
+        const TX *xb = reinterpret_cast<const TX *>(ln->xbias);
+        float b8[VEC], o8[VEC];
+        if (a0) {
+            if (PRE) unpack_f32<TX, VEC>(pre.xb0, b8); else load_pack<TX, VEC>(xb + c0, b8);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) o8[e] = __fadd_rn(to_f32(from_f32<TX>(acc0[e])), b8[e]);
+            store_pack<TX, VEC>(orow + c0, o8);
+        }
+        if (a1) {
+            if (PRE) unpack_f32<TX, VEC>(pre.xb1, b8); else load_pack<TX, VEC>(xb + c1, b8);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) o8[e] = __fadd_rn(to_f32(from_f32<TX>(acc1[e])), b8[e]);
+            store_pack<TX, VEC>(orow + c1, o8);
+        }
+    } else {
+        if (a0) store_pack<TX, VEC>(orow + c0, acc0);
+        if (a1) store_pack<TX, VEC>(orow + c1, acc1);
+    }
+    if (OP == OP_WAVG && lane == 0) store_size<TS>(srow, lrow, ssum);
+    if (LN) {
+        // LayerNorm of the row as stored (rounded to the token dtype), the whole row is in this wave
+        float part = 0.0f;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            acc0[e] = a0 ? to_f32(from_f32<TX>(acc0[e])) : 0.0f;
+            acc1[e] = a1 ? to_f32(from_f32<TX>(acc1[e])) : 0.0f;
+            part += acc0[e] + acc1[e];
+        }
+        const float mean = wave_sum(part) / (float)C;
+        part = 0.0f;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            const float d0 = a0 ? acc0[e] - mean : 0.0f, d1 = a1 ? acc1[e] - mean : 0.0f;
+            part += d0 * d0 + d1 * d1;
+        }
+        const float rstd = 1.0f / __builtin_sqrtf(wave_sum(part) / (float)C + ln->eps);
+        const TX *lw = reinterpret_cast<const TX *>(ln->weight), *lb = reinterpret_cast<const TX *>(ln->bias);
+        if (a0) {
+            float w8[VEC], b8[VEC];
+            if (PRE) { unpack_f32<TX, VEC>(pre.w0, w8); unpack_f32<TX, VEC>(pre.b0, b8); }
+            else { load_pack<TX, VEC>(lw + c0, w8); load_pack<TX, VEC>(lb + c0, b8); }
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) acc0[e] = (acc0[e] - mean) * rstd * w8[e] + b8[e];
+            store_pack<TX, VEC>(yrow + c0, acc0);
+        }
+        if (a1) {
+            float w8[VEC], b8[VEC];
+            if (PRE) { unpack_f32<TX, VEC>(pre.w1, w8); unpack_f32<TX, VEC>(pre.b1, b8); }
+            else { load_pack<TX, VEC>(lw + c1, w8); load_pack<TX, VEC>(lb + c1, b8); }
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) acc1[e] = (acc1[e] - mean) * rstd * w8[e] + b8[e];
+            store_pack<TX, VEC>(yrow + c1, acc1);
+        }
+    }
+}
+
+// merge_dst_row for the launches whose whole index list fits one lane each (r <= 64) and whose rows are at most two
+// 16-byte chunks per lane: the form the edge waves of TimeSformer / Motionformer's frame groups run (196 tokens, r up to
+// 32: a third to all of the destinations receive sources, so this path IS the kernel there).  merge_dst_row walks five
+// dependent memory round trips (dst_idx[k] -> own row | dst_idx scan -> src_idx -> source sizes -> source rows); here
+// lane L holds dst_idx[L], src_idx[L] and the keep flag of rank L from ONE batch of loads, every decision (is k the first
+// edge into its destination, which ranks merge into it, in which order) is a ballot over registers, and the second
+// batch holds everything else at once: the own row, the first NB source rows (with their residual rows), all sizes, the
+// bias / LayerNorm constants.  Two round trips.  Arithmetic and order are merge_dst_row's (own term, then the sources
+// in rank = lane order; shared tail dst_row_finish), so the rows are bit-identical.
+// Returns without doing anything when rank k is not the first edge into its destination.
+template <typename TX, typename TS, int VEC, int OP, bool LN>
+__device__ __forceinline__ void merge_dst_row_r64(const TX *__restrict__ xg, const TS *__restrict__ sg, int C,
+                                                  int64_t tstride, int r, int g, int k,
+                                                  const int64_t *__restrict__ srcg, const int64_t *__restrict__ dstg,
+                                                  const uint8_t *__restrict__ keep, TX *__restrict__ og,
+                                                  int64_t ostride, TS *__restrict__ sog, TS *__restrict__ log, int U,
+                                                  int distill, int lane, const LnArgs *ln, TX *__restrict__ yg,
+                                                  const TX *__restrict__ ag, int64_t astride) {
+    typedef Pack<TX, VEC> __attribute__((aligned(sizeof(TX) * VEC))) PK;
+#ifndef TOME_R64_NB
+#define TOME_R64_NB 1
+#endif
+    constexpr int NB = TOME_R64_NB;  // source rows requested together with the own row
+    // ---- batch 1: the group's index lists, one rank per lane
+    const int li = lane < r ? lane : 0;
+    const int d_l = lane < r ? (int)dstg[li] : -1;
+    const int s_l = (int)srcg[li];
+    const int keep_l = keep ? (int)keep[(int64_t)g * r + li] : 1;
+    const int j = __builtin_amdgcn_readlane(d_l, k);
+    const unsigned long long mk = __ballot(d_l == j);  // the ranks that merge into j, rank order = bit order
+    if ((int)__ffsll((long long)mk) - 1 != k) return;  // an earlier rank builds this destination
+    const bool kill = keep && OP != OP_DROP && (__ballot((d_l == j) && keep_l == 0) != 0ull);
+    // ---- batch 2: everything the row needs
+    const int t = 2 * j + 1;
+    const bool has_s = (OP == OP_WAVG) && sg;
+    const TS sz_raw = (has_s ? sg : reinterpret_cast<const TS *>(xg))[has_s ? 2 * s_l : 0];  // size of rank `lane`'s source
+    const TS own_raw = (has_s ? sg : reinterpret_cast<const TS *>(xg))[has_s ? t : 0];
+    const int c0 = lane * VEC, c1 = (WAVE + lane) * VEC;
+    const bool a0 = c0 < C, a1 = c1 < C;
+    const int c0s = a0 ? c0 : 0, c1s = a1 ? c1 : 0;  // (loads are unconditional: a lane without a chunk re-reads column 0)
+    const bool add = LN && ag;
+    const TX *xr = xg + (int64_t)t * tstride;
+    const TX *ar = add ? ag + (int64_t)t * astride : xr;
+    const PK x0 = *reinterpret_cast<const PK *>(xr + c0s), x1 = *reinterpret_cast<const PK *>(xr + c1s);
+    PK y0 = x0, y1 = x1;
+    if (add) { y0 = *reinterpret_cast<const PK *>(ar + c0s); y1 = *reinterpret_cast<const PK *>(ar + c1s); }
+    unsigned long long rest = mk;
+    int bsel[NB];
+    bool have[NB];
+    PK p0[NB], p1[NB], q0[NB], q1[NB];
+#pragma unroll
+    for (int u = 0; u < NB; ++u) {
+        have[u] = rest != 0ull;
+        bsel[u] = have[u] ? (int)__ffsll((long long)rest) - 1 : k;
+        rest = have[u] ? (rest & (rest - 1ull)) : rest;
+        const int tsu = 2 * __builtin_amdgcn_readlane(s_l, bsel[u]);
+        const TX *sr = xg + (int64_t)tsu * tstride;
+        p0[u] = *reinterpret_cast<const PK *>(sr + c0s);
+        p1[u] = *reinterpret_cast<const PK *>(sr + c1s);
+        if (add) {
+            const TX *sa = ag + (int64_t)tsu * astride;
+            q0[u] = *reinterpret_cast<const PK *>(sa + c0s);
+            q1[u] = *reinterpret_cast<const PK *>(sa + c1s);
+        }
+    }
+    RowConsts<TX, VEC> rc;
+    if (LN) {
+        // (every field is loaded, the bias chunks from the weight when there is no folded bias: no conditional
+        // initialisation, so the struct lives in registers)
+        const TX *lw = reinterpret_cast<const TX *>(ln->weight), *lb = reinterpret_cast<const TX *>(ln->bias);
+        const TX *xb = ln->xbias ? reinterpret_cast<const TX *>(ln->xbias) : lw;
+        rc.w0 = *reinterpret_cast<const PK *>(lw + c0s);
+        rc.w1 = *reinterpret_cast<const PK *>(lw + c1s);
+        rc.b0 = *reinterpret_cast<const PK *>(lb + c0s);
+        rc.b1 = *reinterpret_cast<const PK *>(lb + c1s);
+        rc.xb0 = *reinterpret_cast<const PK *>(xb + c0s);
+        rc.xb1 = *reinterpret_cast<const PK *>(xb + c1s);
+    }
+    // ---- arithmetic, merge_dst_row's order
+    const float sz_l = has_s ? to_f32(sz_raw) : 1.0f;
+    const float s_own = has_s ? to_f32(own_raw) : 1.0f;
+    float acc0[VEC], acc1[VEC];
+    {
+        const Pack<TX, VEC> s0 = add ? add_packs<TX, VEC>(x0, y0) : (Pack<TX, VEC>)x0;
+        const Pack<TX, VEC> s1 = add ? add_packs<TX, VEC>(x1, y1) : (Pack<TX, VEC>)x1;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            acc0[e] = to_f32(s0.e[e]);
+            acc1[e] = to_f32(s1.e[e]);
+        }
+    }
+    float ssum = s_own;
+    int cnt = 1;
+    if (OP == OP_WAVG) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            acc0[e] = __fmul_rn(acc0[e], s_own);
+            acc1[e] = __fmul_rn(acc1[e], s_own);
+        }
+    }
+    if (kill) {
+        if (OP == OP_WAVG) ssum = __fmul_rn(ssum, 0.0f);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            acc0[e] = __fmul_rn(acc0[e], 0.0f);
+            acc1[e] = __fmul_rn(acc1[e], 0.0f);
+        }
+    }
+    for (;;) {
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            if (!have[u]) continue;  // (wave-uniform)
+            const float sq = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(sz_l), bsel[u]));
+            const Pack<TX, VEC> v0 = add ? add_packs<TX, VEC>(p0[u], q0[u]) : (Pack<TX, VEC>)p0[u];
+            const Pack<TX, VEC> v1 = add ? add_packs<TX, VEC>(p1[u], q1[u]) : (Pack<TX, VEC>)p1[u];
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                const float f0 = to_f32(v0.e[e]), f1 = to_f32(v1.e[e]);
+                acc0[e] = reduce_step<OP>(acc0[e], (OP == OP_WAVG) ? __fmul_rn(f0, sq) : f0);
+                acc1[e] = reduce_step<OP>(acc1[e], (OP == OP_WAVG) ? __fmul_rn(f1, sq) : f1);
+            }
+            if (OP == OP_WAVG) ssum = __fadd_rn(ssum, sq);
+            ++cnt;
+        }
+        if (rest == 0ull) break;
+        // a destination with more than NB sources (rare): the next NB, one more round trip
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            have[u] = rest != 0ull;
+            bsel[u] = have[u] ? (int)__ffsll((long long)rest) - 1 : k;
+            rest = have[u] ? (rest & (rest - 1ull)) : rest;
+            const int tsu = 2 * __builtin_amdgcn_readlane(s_l, bsel[u]);
+            const TX *sr = xg + (int64_t)tsu * tstride;
+            p0[u] = *reinterpret_cast<const PK *>(sr + c0s);
+            p1[u] = *reinterpret_cast<const PK *>(sr + c1s);
+            if (add) {
+                const TX *sa = ag + (int64_t)tsu * astride;
+                q0[u] = *reinterpret_cast<const PK *>(sa + c0s);
+                q1[u] = *reinterpret_cast<const PK *>(sa + c1s);
+            }
+        }
+    }
+    const int o = out_row_dst(j, U, distill);
+    dst_row_finish<TX, TS, VEC, OP, LN, LN>(acc0, acc1, a0, a1, c0, c1, ssum, cnt, C, og + (int64_t)o * ostride,
+                                            sog ? sog + o : nullptr, log ? log + o : nullptr, ln,
+                                            LN ? yg + (int64_t)o * ostride : nullptr, lane, rc);
+}
+
 // One destination row (odd token 2j+1 plus every source merged into it), whole wave, contract order:
 // own term first, then the sources in src_idx (rank) order found by ballot-scanning dst_idx.
 // Two shapes of the same arithmetic:
@@ -395,75 +633,7 @@ __device__ __forceinline__ void merge_dst_row(const TX *__restrict__ xg, const T
                 }
             }
         }
-        if (OP == OP_WAVG) {
-#pragma unroll
-            for (int e = 0; e < VEC; ++e) {
-                if (a0) acc0[e] = __fdiv_rn(acc0[e], ssum);
-                if (a1) acc1[e] = __fdiv_rn(acc1[e], ssum);
-            }
-        } else if (OP == TOME_MEAN && cnt > 1) {
-            const float fc = (float)cnt;
-#pragma unroll
-            for (int e = 0; e < VEC; ++e) {
-                if (a0) acc0[e] = __fdiv_rn(acc0[e], fc);
-                if (a1) acc1[e] = __fdiv_rn(acc1[e], fc);
-            }
-        }
-        if (LN && ln->xbias) {
-            const TX *xb = reinterpret_cast<const TX *>(ln->xbias);
-            float b8[VEC], o8[VEC];
-            if (a0) {
-                load_pack<TX, VEC>(xb + c0, b8);
-#pragma unroll
-                for (int e = 0; e < VEC; ++e) o8[e] = __fadd_rn(to_f32(from_f32<TX>(acc0[e])), b8[e]);
-                store_pack<TX, VEC>(orow + c0, o8);
-            }
-            if (a1) {
-                load_pack<TX, VEC>(xb + c1, b8);
-#pragma unroll
-                for (int e = 0; e < VEC; ++e) o8[e] = __fadd_rn(to_f32(from_f32<TX>(acc1[e])), b8[e]);
-                store_pack<TX, VEC>(orow + c1, o8);
-            }
-        } else {
-            if (a0) store_pack<TX, VEC>(orow + c0, acc0);
-            if (a1) store_pack<TX, VEC>(orow + c1, acc1);
-        }
-        if (OP == OP_WAVG && lane == 0) store_size<TS>(srow, lrow, ssum);
-        if (LN) {
-            // LayerNorm of the row as stored (rounded to the token dtype), the whole row is in this wave
-            float part = 0.0f;
-#pragma unroll
-            for (int e = 0; e < VEC; ++e) {
-                acc0[e] = a0 ? to_f32(from_f32<TX>(acc0[e])) : 0.0f;
-                acc1[e] = a1 ? to_f32(from_f32<TX>(acc1[e])) : 0.0f;
-                part += acc0[e] + acc1[e];
-            }
-            const float mean = wave_sum(part) / (float)C;
-            part = 0.0f;
-#pragma unroll
-            for (int e = 0; e < VEC; ++e) {
-                const float d0 = a0 ? acc0[e] - mean : 0.0f, d1 = a1 ? acc1[e] - mean : 0.0f;
-                part += d0 * d0 + d1 * d1;
-            }
-            const float rstd = 1.0f / __builtin_sqrtf(wave_sum(part) / (float)C + ln->eps);
-            const TX *lw = reinterpret_cast<const TX *>(ln->weight), *lb = reinterpret_cast<const TX *>(ln->bias);
-            if (a0) {
-                float w8[VEC], b8[VEC];
-                load_pack<TX, VEC>(lw + c0, w8);
-                load_pack<TX, VEC>(lb + c0, b8);
-#pragma unroll
-                for (int e = 0; e < VEC; ++e) acc0[e] = (acc0[e] - mean) * rstd * w8[e] + b8[e];
-                store_pack<TX, VEC>(yrow + c0, acc0);
-            }
-            if (a1) {
-                float w8[VEC], b8[VEC];
-                load_pack<TX, VEC>(lw + c1, w8);
-                load_pack<TX, VEC>(lb + c1, b8);
-#pragma unroll
-                for (int e = 0; e < VEC; ++e) acc1[e] = (acc1[e] - mean) * rstd * w8[e] + b8[e];
-                store_pack<TX, VEC>(yrow + c1, acc1);
-            }
-        }
+        dst_row_finish<TX, TS, VEC, OP, LN>(acc0, acc1, a0, a1, c0, c1, ssum, cnt, C, orow, srow, lrow, ln, yrow, lane);
         return;
     }
 
@@ -624,6 +794,15 @@ __global__ __launch_bounds__(256) void k_merge_rows(const TX *__restrict__ x, co
 #define FAST_NIT 6
 #define FAST_MAXR 4
 
+// How the hardware workgroups of a k_merge_rows_fast launch map onto (group, block of the group).  on = 0: grid
+// (blocks of one group, group.y, group.z) as launched.  on = 1: a 1-D grid of 8 * per_xcd workgroups renumbered so that
+// each of the 8 XCDs (workgroup L -> XCD L % 8) walks whole groups in order.
+struct MergeSched {
+    unsigned bpg, total, per_xcd;  // blocks per group, bpg * (groups + class-row block rows), ceil(total / 8)
+    int on;
+    unsigned long long magic;      // ceil(2^40 / bpg)
+};
+
 // EAGER (round 3): when r is a large share of the destinations (TimeSformer / Motionformer late layers, r = 32 sweeps:
 // r >= T2 / 4) the streaming waves first wait for dst_idx and do NOT read the rows that receive sources -- those are
 // read (own row + sources) by the edge waves anyway; without it they were read twice (measured, tools/regroup_layers.py:
@@ -637,7 +816,8 @@ __global__ __launch_bounds__(256) void k_merge_rows_fast(const TX *__restrict__ 
                                                          const int64_t *__restrict__ unm_idx, int distill,
                                                          const uint8_t *__restrict__ keep, TX *__restrict__ xout,
                                                          TS *__restrict__ sout, TokLayout lin, TokLayout lout,
-                                                         int cls_rows, LnArgs ln, TS *__restrict__ lsout) {
+                                                         int cls_rows, LnArgs ln, TS *__restrict__ lsout,
+                                                         MergeSched sch) {
     constexpr int VEC = 16 / sizeof(TX);
     const int lane = threadIdx.x & 63;
     const int To = T_ - r;
@@ -647,11 +827,25 @@ __global__ __launch_bounds__(256) void k_merge_rows_fast(const TX *__restrict__ 
     // tokens kept aside by the regrouped callers are handled by the blocks of the (y, z) rows behind the n groups.
     // (rg_per_group = ceil((T - r) / R), from the host)
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int gy = (int)(blockIdx.z * gridDim.y + blockIdx.y);
-    const int lw = (int)blockIdx.x * (int)(blockDim.x >> 6) + wv;
+    int gy, bx;
+    if (sch.on) {
+        // XCD-aware numbering (MergeSched): hardware workgroup L runs on XCD L % 8; virtual block V walks the groups in
+        // order WITHIN one XCD, so an XCD works on whole groups (their index lists stay in its L2) and every XCD sees the
+        // same mix of streaming and edge blocks at any time, whatever gridDim.x is
+        const unsigned L = blockIdx.x;
+        const unsigned V = (L & 7u) * sch.per_xcd + (L >> 3);
+        if (V >= sch.total) return;
+        const unsigned q = (unsigned)(((unsigned long long)V * sch.magic) >> 40);  // V / bpg (exact: V * bpg < 2^40)
+        gy = (int)q;
+        bx = (int)(V - q * sch.bpg);
+    } else {
+        gy = (int)(blockIdx.z * gridDim.y + blockIdx.y);
+        bx = (int)blockIdx.x;
+    }
+    const int lw = bx * (int)(blockDim.x >> 6) + wv;
     if (gy >= n) {
         // the class tokens kept aside by the regrouped callers (timesformer.py:89,107): plain row copies
-        const int64_t b = ((int64_t)(gy - n) * gridDim.x + blockIdx.x) * (blockDim.x >> 6) + wv;
+        const int64_t b = ((int64_t)(gy - n) * sch.bpg + bx) * (blockDim.x >> 6) + wv;
         if (b < cls_rows) {
             const uint4 *src = reinterpret_cast<const uint4 *>(x + b * lin.outer_stride);
             uint4 *dst = reinterpret_cast<uint4 *>(xout + b * lout.outer_stride);
@@ -730,6 +924,20 @@ __global__ __launch_bounds__(256) void k_merge_rows_fast(const TX *__restrict__ 
         const int k = lw - rg_per_group;
         if (OP == OP_DROP || k >= r) return;
         const int64_t *dstg = dst_idx + (int64_t)g * r;
+        if (r <= WAVE && cpr <= 2 * WAVE) {
+            // the whole index list in one lane each: two memory round trips instead of five (merge_dst_row_r64)
+            const int T1e = (T_ + 1) >> 1;
+            const bool add = LN && ln.addend;
+            merge_dst_row_r64<TX, TS, VEC, OP, LN>(
+                group_ptr(x, lin, g), size ? size + (int64_t)g * T_ : nullptr, C, lin.tok_stride, r, g, k,
+                src_idx + (int64_t)g * r, dstg, keep, group_ptr(xout, lout, g), lout.tok_stride,
+                sout ? sout + (int64_t)g * To : nullptr, lsout ? lsout + (int64_t)g * To : nullptr, T1e - r, distill, lane,
+                &ln, LN ? group_ptr(reinterpret_cast<TX *>(ln.y), lout, g) : nullptr,
+                add ? (ln.a_own ? group_ptr(reinterpret_cast<const TX *>(ln.addend), ln.la, g)
+                                : group_ptr(reinterpret_cast<const TX *>(ln.addend), lin, g)) : nullptr,
+                ln.a_own ? ln.la.tok_stride : lin.tok_stride);
+            return;
+        }
         const int j = (int)dstg[k];
         bool earlier = false;
         for (int base = 0; base < k; base += WAVE) {
