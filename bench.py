@@ -435,6 +435,10 @@ def also_workloads(dev, quick: bool = False):
         clips = torch.rand(batch, 3, frames, 224, 224, device=dev).to(torch.bfloat16)
         entry = {"workload": f"{fam}, bf16, random init, synthetic clips, {batch} clips per step", "tokens": tokens,
                  "merge_groups_per_clip": groups}
+        if host == "vivit":
+            entry["parity"] = ("block-level parity UNPINNED: the reference's tome/patch/vivit.py needs HF VivitSelfAttention, "
+                               "absent from the installed transformers, and the reference holds no fixture; the merge "
+                               "call itself (3137 tokens, class token) is pinned like every other")
         for r in rs:
             model.r = r
             rec = _throughput(model, clips, steps, warm)
@@ -494,23 +498,29 @@ def roofline_of(stats, batch: int):
     name = max(stats, key=lambda k: stats[k]["ms"])
     s = stats[name]
     sec = s["ms"] / 1e3
-    traffic = None
+    traffic, traffic_source = None, None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
         try:
             tj = json.load(open(tpath))
-            # PMC bytes are per launch at the batch they were collected on: only quoted for that batch
-            traffic = tj.get(name) if tj.get("_batch", 64) == batch else None
+            # PMC bytes are per launch at the batch they were collected on: only quoted for that batch.  NOT measured
+            # in this run: a stored result of the counter passes of tools/traffic_pmc.sh (rocprofv3 --pmc cannot run
+            # inside the benchmark process), said so in `traffic_source`
+            if tj.get("_batch", 64) == batch and tj.get(name) is not None:
+                traffic = tj.get(name)
+                traffic_source = (f"profiles/traffic.json: stored PMC passes (tools/traffic_pmc.sh, batch {batch}, "
+                                  f"{tj.get('_collected', 'round 3')}), not measured in this run")
         except Exception:
             traffic = None
     if name == "k_scores_rowmax":
         achieved = s["flops"] / sec / 1e12
         return {"kernel": name, "bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_F32_PEAK_TFLOPS,
                 "unit": "TFLOP/s", "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4), "traffic": traffic,
-                "launches_per_step": s["launches"], "avg_launch_us": round(s["ms"] * 1e3 / s["launches"], 2)}
+                "traffic_source": traffic_source, "launches_per_step": s["launches"], "avg_launch_us": round(s["ms"] * 1e3 / s["launches"], 2)}
     achieved = s["bytes"] / sec / 1e9
     out = {"kernel": name, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-           "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "launches_per_step": s["launches"],
+           "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
+           "launches_per_step": s["launches"],
            "avg_launch_us": round(s["ms"] * 1e3 / s["launches"], 2), "bytes_fused": s["bytes"]}
     if s.get("bytes_8d"):
         # the same launches priced on the merge-only bytes of SURVEY.md 8d (the fused launch also reads the residual
@@ -561,6 +571,7 @@ def worker(args):
     rank, local_rank, world = launch.check_world(args.gpus)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU path in the product)")
+    launch.require_one_gpu_per_rank(args.backend, world)  # (RCCL with more ranks than GPUs dies inside the library)
     dev_index = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
@@ -637,8 +648,7 @@ def worker(args):
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el.item())
     census = launch.census(dev)  # ranks that answered + the device index of each (collective: every rank calls it)
-    if census["ranks_seen"] != world:
-        raise SystemExit(f"{census['ranks_seen']} ranks answered, {world} expected")
+    launch.check_census(census, args.backend, world)  # all ranks answered; under RCCL on distinct devices
     total_clips = int(counts[2].item())
     assert total_clips == B * args.steps * world, (total_clips, B, args.steps, world)
 
@@ -704,10 +714,27 @@ def worker(args):
             out["merge_path_kernels"]["k_scores_rowmax"]["stage"] = (
                 "similarity + row max of the matching, as one timed stage: k_scores_filter (approximate scores on the "
                 "bf16 matrix pipe, candidate columns per row) + k_exact_rows (the contract's fp32 chain for the "
-                "candidates) + k_units_from_means / k_scores_rowmax for tiles whose candidate lists overflowed (none on "
+                "candidates; its fallback waves take the fp32 pass of tiles whose candidate lists overflowed -- none on "
                 "this data); TFLOP/s = SURVEY 8d's 2*T1*T2*D per group / stage time, i.e. what an all-pairs fp32 pass "
                 "would have to sustain (peak of that pipe: 157.3)")
             out["merge_path_ms_per_step"] = round(sum(v["ms"] for v in stats.values()), 4)
+            # the PATH as SURVEY 8d prices it: per merge call read metric, x, size once and write x', size' once -- summed
+            # over the 12 layers -- against the time of every launch of matching + merge (the second residual's
+            # k_add_ln_rows is a block-wrapper pass, not part of 8d's path, and is left out of both sides)
+            sched = [(t, re) for t, re in token_schedule(t0_tokens, args.r, LAYERS) if re > 0]
+            bytes_8d = sum(B * (t * HEAD_DIM * 2 + t * EMBED * 2 + t * 2 + (t - re) * EMBED * 2 + (t - re) * 2)
+                           for t, re in sched)
+            path_ms = sum(stats[k]["ms"] for k in ("k_unit_rows_heads", "k_scores_rowmax", "k_rank_select", "k_merge_rows"))
+            filt = B * ((t0_tokens + 1) // 2 + 31) // 32 >= 1024
+            out["merge_path"] = {
+                "bytes_8d_per_step": bytes_8d, "ms_per_step": round(path_ms, 4),
+                "achieved_8d": round(bytes_8d / (path_ms / 1e3) / 1e9, 1), "unit": "GB/s",
+                "frac_8d": round(bytes_8d / (path_ms / 1e3) / 1e9 / HBM_PEAK_GBS, 4),
+                "launches_per_layer": (4 if filt else 3) + 1,
+                "launches": ("k_unit_rows_f, k_scores_filter, k_exact_rows (+ fp32 fallback waves), k_rank_select"
+                             if filt else "k_unit_rows_heads, k_scores_rowmax, k_rank_select") + ", k_merge_rows_fast<LN>",
+                "note": "SURVEY 8d bytes of the 12 merge calls / time of all their launches (matching stages timed inside "
+                        "tome_match_keys, the merge kernel inside the forward); call counts: profiles/r04_*kernel_stats*"}
             with torch.no_grad():
                 out["attention_kernel"] = measure_attention(B, t0_tokens, args.r, dev)
         if world == 1 and not args.no_also:

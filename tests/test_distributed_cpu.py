@@ -163,3 +163,62 @@ def test_bench_spawns_when_started_plainly(monkeypatch):
     monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2", "--backend", "gloo"])
     bench.main()
     assert calls[0][0] is bench.worker and calls[0][1] == 2 and calls[0][2][0].backend == "gloo"
+
+
+def _world8_rank(out_dir, failing_rank):
+    """A rank of the 8-rank job: group over gloo, census, the job's one all-reduce; `failing_rank` raises before the
+    collectives (the others must not hang the parent: mp.spawn tears the job down and re-raises)."""
+    sys.path.insert(0, os.path.join(ROOT, "video-how-do-your-tokens-merge_amd"))
+    from hosts import launch
+    from hosts.evalloop import all_reduce_counts
+    rank, local, world = launch.check_world(8)
+    if rank == failing_rank:
+        raise RuntimeError(f"rank {rank} fails on purpose")
+    launch.init_process_group("gloo")
+    seen = launch.census(torch.device("cpu"))
+    launch.check_census(seen, "gloo", world)
+    counts = torch.tensor([rank, 1, 2], dtype=torch.int64)
+    all_reduce_counts(counts)
+    torch.save({"rank": rank, "local": local, "seen": seen, "counts": counts, "port": os.environ["MASTER_PORT"],
+                "local_world": os.environ["LOCAL_WORLD_SIZE"]}, os.path.join(out_dir, f"w8_{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_launcher_world_8_and_a_failing_rank(tmp_path, monkeypatch):
+    """hosts.launch.run with EIGHT ranks (the size of the scaling run) on CPU / gloo: one free port for all, the rank
+    environment of every child, the census of 8, the one all-reduce, join -- and a rank that raises makes the PARENT
+    raise (no silent partial job, no hang)."""
+    from hosts import launch
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "LOCAL_WORLD_SIZE"):
+        monkeypatch.delenv(k, raising=False)
+    launch.run(_world8_rank, 8, (str(tmp_path), -1))
+    got = [torch.load(os.path.join(str(tmp_path), f"w8_{r}.pt"), weights_only=True) for r in range(8)]
+    assert [g["rank"] for g in got] == list(range(8)) and [g["local"] for g in got] == list(range(8))
+    assert all(g["seen"] == {"ranks_seen": 8, "devices": [-1] * 8} for g in got)
+    assert all(g["counts"].tolist() == [28, 8, 16] for g in got)
+    assert len({g["port"] for g in got}) == 1 and all(g["local_world"] == "8" for g in got)
+    with pytest.raises(Exception, match="fails on purpose"):
+        launch.run(_world8_rank, 8, (str(tmp_path), 3))
+
+
+def test_rccl_refuses_more_ranks_than_gpus_and_stacked_devices(monkeypatch):
+    """bench.py / hosts.harness refuse an RCCL job with more ranks on the node than GPUs before the process group
+    exists (ranks stacked on one device die inside RCCL instead of saying so), and a finished RCCL job whose census
+    shows two ranks on one device is an error; gloo may share a device (dry runs of the N > 1 path)."""
+    from hosts import launch
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 1)
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "2")
+    with pytest.raises(SystemExit, match="one GPU per rank"):
+        launch.require_one_gpu_per_rank("nccl", 2)
+    launch.require_one_gpu_per_rank("gloo", 2)
+    launch.require_one_gpu_per_rank("nccl", 1)
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 8)
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "8")
+    launch.require_one_gpu_per_rank("nccl", 8)
+    launch.check_census({"ranks_seen": 8, "devices": list(range(8))}, "nccl", 8)
+    with pytest.raises(SystemExit, match="not one GPU per rank"):
+        launch.check_census({"ranks_seen": 8, "devices": [0, 1, 2, 3, 4, 5, 6, 6]}, "nccl", 8)
+    launch.check_census({"ranks_seen": 2, "devices": [0, 0]}, "gloo", 2)
+    with pytest.raises(SystemExit, match="ranks answered"):
+        launch.check_census({"ranks_seen": 7, "devices": list(range(7))}, "nccl", 8)

@@ -1076,3 +1076,52 @@ def test_block_output_with_and_without_the_fc2_fold_bf16(host_name, monkeypatch)
         compared += 1
     print(f"{host_name}: {compared} block outputs compared")
     assert compared >= 1
+
+
+def test_closures_and_patches_are_differentiable_when_tokens_require_grad():
+    """SURVEY 8b / tome/merge.py:49: only the matching is no_grad in the reference; `tools/train_net.py:727-741` patches
+    models for training.  With tokens that require grad the closures of this package run on the framework's
+    differentiable ops (the matching still on the HIP kernels): same values as the kernels' inference path, the same
+    gradients as the reference's op sequence (oracle/torch_port.py on CPU with the same index tensors), and a patched
+    model's forward + backward reaches every parameter -- also through the regrouped reductions of TimeSformer."""
+    tome, H = _hosts()
+    from oracle import torch_port
+    from tome import merge as M
+    g = torch.Generator(device=DEV).manual_seed(5)
+    metric = torch.randn(4, 197, 64, device=DEV, generator=g)
+    x = torch.randn(4, 197, 96, device=DEV, generator=g)
+    size = torch.randint(1, 4, (4, 197, 1), device=DEV, generator=g).float()
+    merge, unmerge = M.bipartite_soft_matching(metric, 16, class_token=True)
+    with torch.no_grad():
+        want_x, want_s = M.merge_wavg(merge, x, size)           # the kernels
+    xg = x.clone().requires_grad_(True)
+    got_x, got_s = M.merge_wavg(merge, xg, size)                # framework ops, differentiable
+    assert got_x.requires_grad and torch.equal(got_s, want_s)
+    torch.testing.assert_close(got_x, want_x, rtol=1e-6, atol=1e-6)
+    got_x.square().sum().backward()
+    p = merge.plan
+    tp = torch_port.TorchPlan(p.r, p.src_idx.cpu(), p.dst_idx.cpu(), p.unm_idx.cpu(), p.T)
+    xc = x.cpu().requires_grad_(True)
+    ref_x, _ = torch_port.merge_wavg(tp, xc, size.cpu())
+    ref_x.square().sum().backward()
+    torch.testing.assert_close(xg.grad.cpu(), xc.grad, rtol=1e-5, atol=1e-6)
+    back = unmerge(got_x.detach().requires_grad_(True))
+    assert back.shape == x.shape and back.requires_grad
+    # a patched model trains: VideoMAE (grouped reduction) and TimeSformer (regrouped reduction by views)
+    torch.manual_seed(0)
+    for name, model, clip, patch in (
+            ("videomae", H["videomae"].VideoMAE(num_frames=8, img_size=64, patch_size=16, embed_dim=64, depth=3,
+                                                num_heads=1, num_classes=9), torch.rand(2, 3, 8, 64, 64), tome.patch.videomae),
+            ("timesformer", H["timesformer"].TimeSformer(num_frames=4, img_size=64, patch_size=8, embed_dim=64, depth=3,
+                                                         num_heads=1, num_classes=9), torch.rand(2, 3, 4, 64, 64),
+             tome.patch.timesformer)):
+        model = model.to(DEV).train()
+        patch(model)
+        model.r = 6
+        out = model([clip.to(DEV)])
+        assert out.requires_grad, name
+        out.square().sum().backward()
+        missing = [n for n, q in model.named_parameters() if q.grad is None or not torch.isfinite(q.grad).all()]
+        # (parameters the architecture never reads in this configuration may legitimately have no gradient)
+        assert not [n for n in missing if "blocks" in n and ("qkv" in n or "mlp" in n or "norm" in n)], (name, missing)
+        assert model._tome_info["size"].shape[1] < (196 if name == "videomae" else 64)

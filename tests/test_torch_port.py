@@ -43,3 +43,56 @@ def test_port_videomae_token_schedule():
     assert out.shape == (2, 7) and torch.isfinite(out).all()
     assert [t for t, _ in trace] == [32, 27, 22, 17]  # 2*4*4 tokens, minus 5 per layer
     assert torch_port.schedule(12, (16, -1)) == [32, 29, 26, 23, 20, 17, 14, 11, 8, 5, 2, 0]
+
+
+def test_differentiable_route_of_the_closures_equals_the_reference_op_sequence():
+    """the reference's `merge` is differentiable (only the index computation is no_grad, merge.py:49).  The
+    product's closures hand tensors that require grad to framework ops (tome.merge._merge_with_autograd /
+    _unmerge_with_autograd) -- held here, on CPU with explicit index tensors, to oracle/torch_port.py (the reference's
+    op sequence, pinned to the golden vectors): same values, same gradients, every reduce mode, drop, hybrid flags."""
+    from types import SimpleNamespace
+
+    from tome import merge as M
+    torch.manual_seed(3)
+    for T, r in ((9, 3), (10, 5), (33, 7), (2, 1)):
+        metric = torch.randn(3, T, 8)
+        tp = torch_port.match(metric, r)
+        plan = SimpleNamespace(n=3, T=T, r=tp.r, src_idx=tp.src_idx, dst_idx=tp.dst_idx, unm_idx=tp.unm_idx,
+                               edge_keep=None, distill_token=False)
+        for mode, ref_mode in (("sum", "sum"), ("mean", "mean"), ("max", "amax"), ("amax", "amax"), ("prod", "prod")):
+            x = torch.randn(3, T, 5, requires_grad=True)
+            x2 = x.detach().clone().requires_grad_(True)
+            got, want = M._merge_with_autograd(plan, x, mode), torch_port.merge(tp, x2, ref_mode)
+            assert torch.equal(got, want), mode
+            (got * got).sum().backward()
+            (want * want).sum().backward()
+            assert torch.equal(x.grad, x2.grad), mode
+        # merge_wavg through a closure-like callable
+        x = torch.randn(3, T, 5, requires_grad=True)
+        x2 = x.detach().clone().requires_grad_(True)
+        size = torch.randint(1, 4, (3, T, 1)).float()
+        merge = lambda t, mode="mean": M._merge_with_autograd(plan, t, mode)  # noqa: E731
+        got, gsize = M.merge_wavg(merge, x, size)
+        want, wsize = torch_port.merge_wavg(tp, x2, size)
+        assert torch.equal(got, want) and torch.equal(gsize, wsize)
+        got.square().sum().backward()
+        want.square().sum().backward()
+        assert torch.equal(x.grad, x2.grad)
+        # drop = the unmerged even tokens, then every odd token (merge.py:257-266)
+        d = M._merge_with_autograd(plan, x.detach(), "sum", keep_sources=False)
+        xe, xo = x.detach()[:, ::2], x.detach()[:, 1::2]
+        assert torch.equal(d, torch.cat([xe.gather(1, tp.unm_idx.expand(3, -1, 5)), xo], 1))
+        # hybrid: a destination with an incoming edge flagged 0 loses its own row first (merge.py:326)
+        keep = torch.randint(0, 2, (3, tp.r), dtype=torch.uint8)
+        hplan = SimpleNamespace(**{**plan.__dict__, "edge_keep": keep})
+        h = M._merge_with_autograd(hplan, x.detach(), "sum")
+        odd = xo.scatter_reduce(1, tp.dst_idx.expand(3, tp.r, 5), keep[..., None].float().expand(3, tp.r, 5), reduce="prod")
+        odd = odd.scatter_reduce(1, tp.dst_idx.expand(3, tp.r, 5), xe.gather(1, tp.src_idx.expand(3, tp.r, 5)), reduce="sum")
+        assert torch.equal(h[:, -xo.shape[1]:], odd)
+        # unmerge puts every destination row back on its odd slot and on the even slots merged into it (merge.py:87-100)
+        y = M._merge_with_autograd(plan, x.detach(), "mean")
+        z = M._unmerge_with_autograd(plan, y.requires_grad_(True))
+        u = (T + 1) // 2 - tp.r
+        assert z.shape == (3, T, 5) and torch.equal(z[:, 1::2], y[:, u:])
+        assert torch.equal(z[:, ::2].gather(1, tp.unm_idx.expand(3, -1, 5)), y[:, :u])
+        assert torch.equal(z[:, ::2].gather(1, tp.src_idx.expand(3, -1, 5)), y[:, u:].gather(1, tp.dst_idx.expand(3, -1, 5)))

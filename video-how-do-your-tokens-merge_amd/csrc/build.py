@@ -44,7 +44,9 @@ def hipcc() -> str:
 def needs_build() -> bool:
     if not os.path.exists(OUT) or not os.path.exists(OUT_PROF):
         return True
-    t = os.path.getmtime(OUT)
+    # the OLDER of the two outputs decides: a measurement build left behind by an earlier, interrupted or failed run
+    # must not be taken for current because the product library next to it is
+    t = min(os.path.getmtime(OUT), os.path.getmtime(OUT_PROF))
     import glob
     deps = SRC + sorted(glob.glob(os.path.join(HERE, "*.h")))  # every kernel header of this directory
     deps += [os.path.join(PKG, "..", "include", "tome_hip.h"), os.path.abspath(__file__)]
@@ -55,15 +57,32 @@ def build(force: bool = False, verbose: bool = False, extra=()) -> str:
     if not force and not needs_build():
         return OUT
     os.makedirs(OUT_DIR, exist_ok=True)
-    cmds = [[hipcc(), *FLAGS, *extra, "-o", OUT, *SRC],
-            [hipcc(), *FLAGS, *extra, "-DTOME_PROFILE_HOOKS", "-o", OUT_PROF, *SRC]]
+    # each compiler writes to a temporary name; the outputs are put in place (os.replace: atomic) only when BOTH
+    # builds have succeeded, so no half-written or stale library is ever bound
+    tmp = [OUT + f".tmp{os.getpid()}", OUT_PROF + f".tmp{os.getpid()}"]
+    cmds = [[hipcc(), *FLAGS, *extra, "-o", tmp[0], *SRC],
+            [hipcc(), *FLAGS, *extra, "-DTOME_PROFILE_HOOKS", "-o", tmp[1], *SRC]]
     if verbose:
-        for cmd in cmds:
-            print(" ".join(cmd), flush=True)
-    procs = [subprocess.Popen(cmd) for cmd in cmds]  # the two builds side by side
-    for proc, cmd in zip(procs, cmds):
-        if proc.wait() != 0:
-            raise subprocess.CalledProcessError(proc.returncode, cmd)
+        for cmd, final in zip(cmds, (OUT, OUT_PROF)):
+            print(" ".join(cmd[:-2] + [final] + cmd[-1:]), flush=True)
+    procs = []
+    try:
+        for cmd in cmds:  # the two builds side by side
+            procs.append(subprocess.Popen(cmd))
+        codes = [proc.wait() for proc in procs]  # every compiler is waited for before anything is decided
+        for code, cmd in zip(codes, cmds):
+            if code != 0:
+                raise subprocess.CalledProcessError(code, cmd)
+        for t, final in zip(tmp, (OUT, OUT_PROF)):
+            os.replace(t, final)
+    finally:
+        for proc in procs:  # (an exception above, e.g. KeyboardInterrupt: no compiler is left running)
+            if proc.poll() is None:
+                proc.kill()
+                proc.wait()
+        for t in tmp:
+            if os.path.exists(t):
+                os.remove(t)
     return OUT
 
 

@@ -151,10 +151,7 @@ def _setup(cfg, dtype: str):
     if not torch.cuda.is_available():
         raise SystemExit("the merge path has no CPU implementation: an MI355X is required")
     backend = os.environ.get("TOME_DIST_BACKEND", getattr(cfg, "DIST_BACKEND", "nccl"))
-    if backend == "nccl" and world > 1 and int(os.environ.get("LOCAL_WORLD_SIZE", world)) > torch.cuda.device_count():
-        # several ranks on one GPU hang or fail inside RCCL instead of saying so
-        raise SystemExit(f"{os.environ.get('LOCAL_WORLD_SIZE', world)} ranks on this node but {torch.cuda.device_count()} GPU(s): "
-                         "RCCL needs one GPU per rank (TOME_DIST_BACKEND=gloo shares a GPU for a dry run)")
+    launch.require_one_gpu_per_rank(backend, world)
     dev = torch.device("cuda", local % torch.cuda.device_count())
     torch.cuda.set_device(dev)
     launch.init_process_group(backend, dev)

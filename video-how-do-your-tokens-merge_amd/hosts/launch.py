@@ -127,3 +127,24 @@ def census(device) -> dict:
     every = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
     dist.all_gather(every, mine)
     return {"ranks_seen": int(one.item()), "devices": [int(t.item()) for t in every]}
+
+
+def require_one_gpu_per_rank(backend: str, world: int) -> None:
+    """RCCL wants one GPU per rank: several ranks stacked on one device hang or fail inside the library instead of saying
+    so.  Refused here, before the process group exists (`--backend gloo` / TOME_DIST_BACKEND=gloo shares a GPU for a dry
+    run of the N > 1 code path).  Counting devices does not initialise the GPU."""
+    import torch
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world))
+    if backend == "nccl" and world > 1 and local_world > torch.cuda.device_count():
+        raise SystemExit(f"{local_world} ranks on this node but {torch.cuda.device_count()} GPU(s): RCCL needs one GPU "
+                         "per rank (the gloo backend shares a GPU for a dry run)")
+
+
+def check_census(seen: dict, backend: str, world: int) -> None:
+    """After the job: every rank answered, and under RCCL the ranks of one node computed on DISTINCT devices."""
+    if seen["ranks_seen"] != world:
+        raise SystemExit(f"{seen['ranks_seen']} ranks answered, {world} expected")
+    single_node = int(os.environ.get("LOCAL_WORLD_SIZE", world)) == world
+    if backend == "nccl" and world > 1 and single_node and len(set(seen["devices"])) != world:
+        raise SystemExit(f"RCCL job of {world} ranks ran on devices {seen['devices']}: not one GPU per rank")
+

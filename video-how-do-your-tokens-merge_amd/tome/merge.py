@@ -15,6 +15,12 @@ The returned ``merge`` / ``unmerge`` / ``drop`` are real closures over ``unm_idx
 so code that introspects them keeps working; they also carry ``.plan`` for the fused paths.
 
 Tensors must live on a HIP device: there is no CPU implementation in this package.
+
+Autograd (only the index computation is ``no_grad`` in the reference, merge.py:49; tools/train_net.py:727-741
+patches models for training): the kernels are inference code.  When a tensor handed to ``merge`` / ``unmerge`` /
+``drop`` / ``merge_wavg`` requires grad (and grad mode is on), the closure applies its index tensors with the
+framework's own differentiable gather / scatter_reduce ops on the tensor's device instead (``_merge_with_autograd``
+below: the op sequence of merge.py:75-100) -- the matching itself always runs on the HIP kernels.
 """
 from __future__ import annotations
 
@@ -103,6 +109,56 @@ def bipartite_soft_matching(
     return _make_merge_pair(plan)
 
 
+def _wants_autograd(x: torch.Tensor) -> bool:
+    return torch.is_grad_enabled() and x.requires_grad
+
+
+_SCATTER_MODE = {"sum": "sum", "mean": "mean", "prod": "prod", "max": "amax", "amax": "amax", "min": "amin", "amin": "amin"}
+
+
+def _interleave_distill(first: torch.Tensor, second: torch.Tensor) -> torch.Tensor:
+    # merge.py:82-83: with a distillation token the class token of `first` and the distill token of `second` lead
+    return torch.cat([first[:, :1], second[:, :1], first[:, 1:], second[:, 1:]], dim=1)
+
+
+def _merge_with_autograd(plan, x: torch.Tensor, mode: str, keep_sources: bool = True) -> torch.Tensor:
+    """The merge (keep_sources) or drop callback on differentiable framework ops: even tokens gathered by
+    ``unm_idx``, sources scattered onto their odd destinations with ``scatter_reduce(include_self=True)``
+    (merge.py:75-85, :257-266), a hybrid matching's threshold flags first (merge.py:326)."""
+    if mode not in _SCATTER_MODE:
+        raise _abi.TomeHipError(f"merge: unknown reduce mode {mode!r}")
+    n, t, c = x.shape
+    if n != plan.n or t != plan.T:
+        raise _abi.TomeHipError(f"merge(x): expected [{plan.n}, {plan.T}, C], got {tuple(x.shape)}")
+    a_rows, b_rows = x[:, 0::2], x[:, 1::2]
+    r, t1 = plan.r, a_rows.shape[1]
+    kept = a_rows.gather(1, plan.unm_idx.expand(n, t1 - r, c))
+    if keep_sources:
+        where = plan.dst_idx.expand(n, r, c)
+        if plan.edge_keep is not None:
+            flags = plan.edge_keep.reshape(n, r, 1).to(x.dtype).expand(n, r, c)
+            b_rows = b_rows.scatter_reduce(1, where, flags, reduce="prod")
+        b_rows = b_rows.scatter_reduce(1, where, a_rows.gather(1, plan.src_idx.expand(n, r, c)),
+                                       reduce=_SCATTER_MODE[mode])
+    if plan.distill_token:
+        return _interleave_distill(kept, b_rows)
+    return torch.cat([kept, b_rows], dim=1)
+
+
+def _unmerge_with_autograd(plan, x: torch.Tensor) -> torch.Tensor:
+    """merge.py:87-100 on differentiable ops: odd slots take the destination rows, even slots their unmerged row or a
+    copy of the destination they were merged into."""
+    n, _, c = x.shape
+    r, t1 = plan.r, (plan.T + 1) // 2
+    u = t1 - r
+    kept, b_rows = x[:, :u], x[:, u:]
+    copies = b_rows.gather(1, plan.dst_idx.expand(n, r, c))
+    a_rows = x.new_zeros((n, t1, c)).scatter(1, plan.unm_idx.expand(n, u, c), kept)
+    a_rows = a_rows.scatter(1, plan.src_idx.expand(n, r, c), copies)
+    return torch.stack([a_rows[:, :b_rows.shape[1]], b_rows], dim=2).flatten(1, 2) if t1 == b_rows.shape[1] \
+        else torch.cat([torch.stack([a_rows[:, :-1], b_rows], dim=2).flatten(1, 2), a_rows[:, -1:]], dim=1)
+
+
 def _make_merge_pair(plan: _abi.MatchPlan) -> Tuple[Callable, Callable]:
     unm_idx, src_idx, dst_idx = plan.unm_idx, plan.src_idx, plan.dst_idx
     r, distill_token = plan.r, plan.distill_token
@@ -111,10 +167,16 @@ def _make_merge_pair(plan: _abi.MatchPlan) -> Tuple[Callable, Callable]:
         # the index tensors are closure variables on purpose (same names as the reference's closure, so
         # `merge.__closure__` introspection keeps working); the kernels read them through `plan`
         _closure = (unm_idx, src_idx, dst_idx, r, distill_token)  # noqa: F841
+        if _wants_autograd(x):
+            return _merge_with_autograd(plan, x, mode)
         return _abi.merge(plan, x, mode)
 
     def unmerge(x: torch.Tensor) -> torch.Tensor:
         _closure = (unm_idx, src_idx, dst_idx, r)  # noqa: F841
+        if _wants_autograd(x):
+            if distill_token:
+                raise _abi.TomeHipError("unmerge: the distillation layout has no differentiable form here")
+            return _unmerge_with_autograd(plan, x)
         return _abi.unmerge(plan, x)
 
     merge.plan = plan
@@ -141,6 +203,8 @@ def bipartite_soft_matching_drop(
 
     def drop(x: torch.Tensor) -> torch.Tensor:
         _closure = (und_idx, src_idx, r, distill_token)  # noqa: F841  (closure variables as in the reference)
+        if _wants_autograd(x):
+            return _merge_with_autograd(plan, x, "sum", keep_sources=False)
         return _abi.drop(plan, x)
 
     drop.plan = plan
@@ -168,6 +232,21 @@ def bipartite_soft_matching_hybrid(
     return merge, unmerge
 
 
+def kth_bipartite_soft_matching(metric: torch.Tensor, k: int):
+    """tome/merge.py:105-158 (every k-th token as destination set).  No patch, driver or notebook of the reference
+    calls it (outside the hot path); the name exists so that `from tome.merge import ...` of code written
+    against the reference fails here, with the reason, instead of at import."""
+    raise _abi.TomeHipError("kth_bipartite_soft_matching is not provided by the MI355X path (no caller in the "
+                            "reference's patches; see INTEGRATION.md, API table)")
+
+
+def random_bipartite_soft_matching(metric: torch.Tensor, r: int):
+    """tome/merge.py:161-212 (a random source set).  As kth_bipartite_soft_matching: present by name, refused loudly.
+    (The random MODES of the patches -- mode='random_merge' / 'random_drop', merge.py:54-57 -- are implemented.)"""
+    raise _abi.TomeHipError("random_bipartite_soft_matching is not provided by the MI355X path (no caller in the "
+                            "reference's patches; use mode='random_merge' of bipartite_soft_matching)")
+
+
 def merge_wavg(merge: Callable, x: torch.Tensor, size: Optional[torch.Tensor] = None, log_size: bool = False
                ) -> Tuple[torch.Tensor, torch.Tensor]:
     """Size-weighted average merge; returns the merged tensor and the new token sizes.  With a merge
@@ -175,9 +254,10 @@ def merge_wavg(merge: Callable, x: torch.Tensor, size: Optional[torch.Tensor] = 
     ``log_size=True`` (not in the reference's signature) makes that launch also emit ``log(size')`` for the
     next block's proportional-attention bias; consumers fetch it with ``_abi.log_of_size(size)``."""
     plan = getattr(merge, "plan", None)
-    if plan is not None:
+    if plan is not None and not (_wants_autograd(x) or (size is not None and _wants_autograd(size))):
         return _abi.merge_wavg(plan, x, size, log_size=log_size)
-    # foreign callables (and do_nothing): the reference's op sequence on the tensors' own device
+    # foreign callables, do_nothing, and tensors that require grad (the closure then runs on the framework's
+    # differentiable ops): the reference's op sequence on the tensors' own device
     if size is None:
         size = torch.ones_like(x[..., 0, None])
     x = merge(x * size, mode="sum")

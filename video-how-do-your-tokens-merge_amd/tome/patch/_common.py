@@ -391,12 +391,31 @@ def merge_then_norm(metric, x, info, norm, reduction_function, plain_merge_fn, r
     return x, norm(x)
 
 
+def _regrouped_by_views(reduce_grouped, metric, x_full, info, r, frames):
+    """The reference's own sequence around a grouped reduction (timesformer.py:89-107, motionformer.py:150-168): split
+    the class token off, '(p t) -> (b t) p', reduce, back, cat.  Differentiable framework ops end to end: the form the
+    regrouped reductions take when the tokens require grad (training, tools/train_net.py:727-741)."""
+    B, N, C = x_full.shape
+    P = (N - 1) // frames
+    body = x_full[:, 1:].reshape(B, P, frames, C).transpose(1, 2).reshape(B * frames, P, C)
+    body = reduce_grouped(metric, body, info, r)
+    P2 = body.shape[1]
+    body = body.reshape(B, frames, P2, C).transpose(1, 2).reshape(B, P2 * frames, C)
+    return torch.cat((x_full[:, :1], body), dim=1)
+
+
+def _training_tokens(x) -> bool:
+    return torch.is_grad_enabled() and x.requires_grad
+
+
 def reduce_merge_regrouped(metric, x_full, info, r, frames, hybrid=False):
     """reduce_merge / reduce_hybrid for the models whose merge groups are interleaved in the token sequence
     (TimeSformer '(p t)', Motionformer '(s f)'): x_full is [B, 1 + P*F, C] with the class token in front; the
     kernel addresses the groups in place and returns [B, 1 + (P-r)*F, C] (no permuted copies of x)."""
     from .. import _abi
     from ..merge import do_nothing
+    if _training_tokens(x_full):
+        return _regrouped_by_views(reduce_hybrid if hybrid else reduce_merge, metric, x_full, info, r, frames)
     if hybrid:
         merge, _ = bipartite_soft_matching_hybrid(metric, r, info["class_token"], info["distill_token"], info["mode"],
                                                   info["threshold"])
@@ -511,6 +530,8 @@ def reduce_drop_regrouped(metric, x_full, info, r, frames: int):
     are addressed in place by the kernel (tome_drop_regrouped) instead of regrouped by permuted copies
     (timesformer.py:111-131, motionformer.py:172-193)."""
     from .. import _abi
+    if _training_tokens(x_full):
+        return _regrouped_by_views(reduce_drop, metric, x_full, info, r, frames)
     drop = bipartite_soft_matching_drop(metric, r, info["class_token"], info["distill_token"], info["mode"])
     if isinstance(drop, tuple):
         return x_full
