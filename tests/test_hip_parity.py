@@ -1061,13 +1061,20 @@ def test_prop_attention_against_fp32_reference(B, H, N, dtype, tol):
         assert float((out.float() - want).abs().max()) <= tol, mode
 
 
-@pytest.mark.parametrize("dtype,tol", [(torch.bfloat16, 1e-2), (torch.float16, 2e-3)])
+@pytest.mark.parametrize("dtype,tol", [(torch.bfloat16, 1.5e-2), (torch.float16, 2e-3)])
 @pytest.mark.parametrize("B,H,P,F", [(2, 3, 196, 8), (1, 2, 36, 4), (1, 12, 64, 8), (2, 1, 100, 3), (1, 2, 5, 2)])
 def test_prop_attention_segments_against_fp32_reference(B, H, P, F, dtype, tol):
     """tome_prop_attention_segments: every query against F key segments of P keys with a softmax per segment
     (the per-frame stage of ToMeTrajectoryAttention.forward, tome/patch/motionformer.py:98-121) == the reference's own
     expression in fp32: q_dot_k regrouped 'b q (f n) -> b q f n', + the flat per-key bias, softmax over n, times v
-    regrouped 'b (f n) d -> b f n d'; q / k / v are views of one qkv buffer behind a class token, as in the patch."""
+    regrouped 'b (f n) d -> b f n d'; q / k / v are views of one qkv buffer behind a class token, as in the patch.
+    Tolerance (bf16): the weights go to the second product rounded to the 16-bit format (relative 2^-9, as the
+    reference's own bf16 `softmax` output is).  The resident-K/V kernel (<= 224 keys, tome_attn_resident.h) takes its
+    reference point from the first 32 keys, so a DOMINANT key in a later block carries a weight 2^x that is rounded
+    (the streaming kernel's first 64-key tile gives such a key the exactly representable weight 1): on a row where one
+    key holds nearly all the mass the output moves by up to 2^-9 |v| ~ 0.006 more.  Measured on random N(0, 1) q / k / v
+    (tools/probes/attn_segment_error.py): mean error identical (4.0e-4), maximum 0.0062-0.0080 streaming, 0.0085-0.0129
+    resident."""
     from tome import _abi
     g = torch.Generator(device=DEV).manual_seed(P * 31 + F)
     N = 1 + P * F

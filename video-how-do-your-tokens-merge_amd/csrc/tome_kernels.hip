@@ -32,6 +32,7 @@
 #include "tome_merge.h"
 #include "tome_attn.h"
 #include "tome_attn_stream.h"
+#include "tome_attn_resident.h"
 
 // ------------------------------------------------------------------------------------------------
 // host side: argument checks, workspace carving, launches
@@ -909,6 +910,29 @@ static int prop_attention_impl(const void *q, const void *k, const void *v, int 
             return fail(TOME_EINVAL, "tome_prop_attention_segments: segment offsets must keep rows 16/8-byte aligned");
         a.k_seg = seg_strides[0]; a.v_seg = seg_strides[1]; a.o_seg = seg_strides[2]; a.ls_seg = seg_strides[3];
     }
+    hipStream_t st = (hipStream_t)stream;
+    // Short key sequences (TimeSformer's 1 + p <= 197 tokens per frame, Motionformer's <= 196 keys per frame segment):
+    // the whole K / V of a (batch, head, segment) resident in LDS, one workgroup per item, no per-tile barrier
+    // (tome_attn_resident.h).  TOME_ATTN_RESIDENT=0 keeps the streaming kernels (measurement switch, read per call).
+    {
+        const char *re = getenv("TOME_ATTN_RESIDENT");
+        // (the kernel addresses the tokens of one (batch, head) slice with 32-bit element offsets)
+        const bool off32 = N * a.q_sn < (1ll << 31) && Nk * a.k_sn < (1ll << 31) && Nk * a.v_sn < (1ll << 31) &&
+                           N * a.o_sn < (1ll << 31);
+        if (Nk <= RES_ROWS && off32 && !(re && re[0] == '0')) {
+            const int64_t items = (B * H + 7) / 8 * 8 * nseg;
+            if (items > 0x7fffffffLL) return fail(TOME_EINVAL, "tome_prop_attention: grid too large");
+            const dim3 rgrid((unsigned)items);
+            if (dtype == TOME_BF16) {
+                if (log_size) hipLaunchKernelGGL((k_resident_attention<bf16_t, true>), rgrid, dim3(512), 0, st, a);
+                else hipLaunchKernelGGL((k_resident_attention<bf16_t, false>), rgrid, dim3(512), 0, st, a);
+            } else {
+                if (log_size) hipLaunchKernelGGL((k_resident_attention<f16_t, true>), rgrid, dim3(512), 0, st, a);
+                else hipLaunchKernelGGL((k_resident_attention<f16_t, false>), rgrid, dim3(512), 0, st, a);
+            }
+            return check_launch("k_resident_attention");
+        }
+    }
     // queries per workgroup: 256 (eight waves share every staged K/V tile: staging costs 18 % with four) unless the
     // sequence is short.  (Measured: 5, 6 or 7 waves per workgroup, chosen to leave no part-empty last block, are
     // 10-30 % slower per block than eight -- uneven staging passes and SIMD load -- and lose more than they save.)
@@ -926,7 +950,6 @@ static int prop_attention_impl(const void *q, const void *k, const void *v, int 
     const int64_t bh8 = (B * H * nseg + 7) / 8 * 8;
     if (bh8 * qblocks > 0x7fffffffLL) return fail(TOME_EINVAL, "tome_prop_attention: grid too large");
     const dim3 grid((unsigned)(bh8 * qblocks));
-    hipStream_t st = (hipStream_t)stream;
     // Eight-wave launches with at least two key tiles run as persistent workgroups, one per CU, that keep the K/V
     // pipeline going across query blocks (tome_attn_stream.h); TOME_ATTN_STREAM=0 keeps one workgroup per block
     // (measurement switch, read per call)
