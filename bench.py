@@ -422,9 +422,12 @@ def also_workloads(dev, quick: bool = False):
     steps, warm = (3, 2) if quick else (12, 6)  # (warm-up also covers the clock ramp after the idle model build)
     plan = [  # (key, family, r values, clips per step)
         ("videomae_b_8x224", "videomae_b_8x224", (16,), 128),
-        ("timesformer_divst_8x224", "timesformer_divst_8x224", (8, 16, 32), 64),
+        # (clips per step chosen like the headline's 384: where clips/s stops growing.  TimeSformer 64 -> 128 -> 192 ->
+        #  256 -> 384: r=8 2452 -> 2582 -> 2622 -> 2666 -> 2684, r=16 3413 -> 3641 -> 3716 -> 3791 -> 3863, r=32 5536 ->
+        #  6107 -> 6294 -> 6510 -> 6704; Motionformer 64 -> 96 -> 128: 2130 -> 2163 -> 2168 -- profiles/r04_batch_scan_*.txt)
+        ("timesformer_divst_8x224", "timesformer_divst_8x224", (8, 16, 32), 384),
         ("vivit_b_32x224", "vivit_b_32x224", (64,), 64),   # (16 -> 64 clips per step: +11 %, GEMM efficiency)
-        ("motionformer_224_16x4", "motionformer_224_16x4", (16,), 64),
+        ("motionformer_224_16x4", "motionformer_224_16x4", (16,), 128),
     ]
     out = {}
     for key, fam, rs, batch in plan:

@@ -506,13 +506,18 @@ static int launch_merge_rows(const void *x, const void *size, int64_t n, int64_t
         const int64_t gy = ny < 65535 ? ny : 65535, gz = (ny + gy - 1) / gy;
         if (gz > 65535) return fail(TOME_EINVAL, "merge: too many groups (%lld)", (long long)n);
         dim3 grid((unsigned)bpg, (unsigned)gy, (unsigned)gz);
-        // XCD-aware numbering of the workgroups (MergeSched, csrc/tome_merge.h) when the launch has several blocks per
-        // group and fits a 1-D grid; TOME_MERGE_XCD=0 keeps the (blocks, group) grid (measurement switch, read per call)
+        // XCD-aware numbering of the workgroups (MergeSched, csrc/tome_merge.h) for the launches where many destinations
+        // receive sources (8 r >= T: TimeSformer / Motionformer frame groups at r = 32, late layers at r = 16) -- there the
+        // edge blocks at the end of every group otherwise land on the same XCDs in every group; measured per layer with
+        // tools/regroup_kernel_times.py: -4 ... -7 % at r = 32, +-1 % at r = 16, +3 % at r = 8 and +3.6 % on the
+        // benchmark's VideoMAE launches (598 vs 577 us), hence not there.  TOME_MERGE_XCD=0 / 1 forces it off / on
+        // (measurement switch, read per call).
         MergeSched sch{(unsigned)bpg, (unsigned)(bpg * ny), 0u, 0, 0ull};
         {
             const char *xe = getenv("TOME_MERGE_XCD");
             const int64_t total = bpg * ny;
-            if (!(xe && xe[0] == '0') && total < (1ll << 28) && bpg < (1ll << 12) && total >= 64) {
+            const bool want = xe ? xe[0] == '1' : (OP != OP_DROP && r <= 64 && 8 * r >= T);
+            if (want && total < (1ll << 28) && bpg < (1ll << 12) && total >= 64) {
                 sch.per_xcd = (unsigned)((total + 7) / 8);
                 sch.on = 1;
                 sch.magic = ((1ull << 40) + (unsigned long long)bpg - 1ull) / (unsigned long long)bpg;
