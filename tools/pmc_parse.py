@@ -35,7 +35,7 @@ def main():
     write = load(sys.argv[2])
     sys.path.insert(0, ROOT)
     import bench
-    batch = int(sys.argv[3]) if len(sys.argv) > 3 else bench.DEFAULT_BATCH
+    batch = int(sys.argv[3]) if len(sys.argv) > 3 and sys.argv[3] else bench.DEFAULT_BATCH
     out = {"_units": f"bytes per launch (mean over the launches of one 12-layer chain, batch {batch})",
            "_correction": "FETCH_SIZE KiB x2 (gfx950 wide-read under-count) + WRITE_SIZE KiB"}
     for k in fetch:
@@ -49,6 +49,8 @@ def main():
         out[k] = {"fetch": round(f), "write": round(w), "total": round(f + w), "launches": len(fetch[k])}
     flat = {k: v["total"] for k, v in out.items() if isinstance(v, dict)}
     flat["_batch"] = batch
+    import datetime
+    flat["_collected"] = sys.argv[4] if len(sys.argv) > 4 else datetime.date.today().isoformat()
     flat["_detail"] = out
     with open(os.path.join(ROOT, "profiles", "traffic.json"), "w") as fh:
         json.dump(flat, fh, indent=1)
