@@ -498,8 +498,12 @@ def test_errors_are_loud():
         merge(torch.randint(0, 5, (2, 16, 8), device=DEV))  # integer tokens
     with pytest.raises(TomeHipError):
         tm.merge_wavg(merge, torch.randn(2, 16, 8, device=DEV), torch.ones(2, 15, 1, device=DEV))  # size shape
+    # tokens that require grad: the closures take the framework's differentiable ops (tome/merge.py, round 4); the
+    # kernels themselves, called directly, still refuse them
+    xg = torch.randn(2, 16, 8, device=DEV, requires_grad=True)
+    assert tm.merge_wavg(merge, xg)[0].requires_grad
     with pytest.raises(TomeHipError):
-        tm.merge_wavg(merge, torch.randn(2, 16, 8, device=DEV, requires_grad=True))  # autograd: inference path only
+        _abi.merge_wavg(merge.plan, xg, None)
     with pytest.raises(TomeHipError):
         tm.bipartite_soft_matching(torch.randn(2, 16, device=DEV), 4)  # metric not [n, T, D]
     with pytest.raises(TomeHipError):

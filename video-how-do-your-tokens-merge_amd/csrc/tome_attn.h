@@ -135,17 +135,13 @@ template <typename TX> __device__ __forceinline__ short att_bits(float f) {
 // pairs, a partly filled one): the same fast step with a run-time slot and out-of-range weights forced to zero.
 // ------------------------------------------------------------------------------------------------
 #define ATT_SLOTS 2
-#ifndef ATT_PRIO
-#define ATT_PRIO 2  // s_setprio(1) while a wave runs the softmax of its step (exp, row sums, packing), 0 around its
-                    // matrix instructions: the partner wave's MFMAs fill in behind.  Measured (tools/ab_lib.sh): 0 = none
-                    // 725-734 / 821-825 TFLOP/s plain, 651 / 690 with the size bias at 128x12x1568 / x1472; 2 = 736-737 /
-                    // 830 and 665-667 / 710; tried and dropped: priority around the MFMAs instead 684 / 786; from the V-fragment
-                    // reads on 726-728 / 781-792; exp only 721-723 / 788-791; a static priority for one wave of
-                    // each SIMD pair instead: no gain plain, -5...-8 % with the bias
-#endif
-#ifndef ATT_ABL
-#define ATT_ABL 0  // measurement builds only (tools/ab_lib.sh): bit 0 no v_exp, 1 no barrier, 2 no V-fragment reads,
-#endif             // 3 no LDS staging writes, 4 no global loads in the fast step -- results are wrong by design
+// s_setprio(1) while a wave runs the softmax of its step (exp, row sums, packing), 0 around its matrix instructions: the
+// partner wave's MFMAs fill in behind.  Measured in round 2 (A/B libraries, one box): none 725-734 / 821-825 TFLOP/s plain,
+// 651 / 690 with the size bias at 128x12x1568 / x1472; this form 736-737 / 830 and 665-667 / 710; tried and dropped:
+// priority around the MFMAs instead 684 / 786; from the V-fragment reads on 726-728 / 781-792; exp only 721-723 /
+// 788-791; a static priority for one wave of each SIMD pair: no gain plain, -5...-8 % with the bias.
+// (The ablation switches of rounds 2-3 -- no v_exp, no barrier, no V-fragment reads, no staging -- are gone from this
+// file; their results are in DESIGN_HISTORY.md.)
 
 template <int V> struct AttInt { static constexpr int value = V; };
 
@@ -386,45 +382,33 @@ __global__ __launch_bounds__(64 * WAVES, 2) void k_prop_attention(AttnArgs a) { 
     //   interleave.  The overflow guard only sets a flag (see below).
     bool bad = false;
     auto fast_step = [&](int S, int t, bool masked) __attribute__((always_inline)) {
-#if !(ATT_ABL & 8)
         stage_write(S);  // registers hold tile t+1
-#endif
         // tile t+2, rows clamped to the last key instead of a bounds branch (a partly filled tile gets its scores
         // masked by the general softmax; its weights are 0, so a repeated V row adds nothing): no control flow
         // between two barriers
 #pragma unroll
         for (int i = 0; i < NST; ++i) {
             const int key = min((t + 2) * ATT_BN + r0 + RSTEP * i, a.Nk - 1);
-#if !(ATT_ABL & 16)
             kreg[i] = *reinterpret_cast<const uint4 *>(kp + (int64_t)key * a.k_sn + 8 * c0);
             vreg[i] = *reinterpret_cast<const uint4 *>(vp + (int64_t)key * a.v_sn + 8 * c0);
-#endif
         }
         if (BIAS && tid < ATT_BN) {
             const int key = min((t + 2) * ATT_BN + tid, a.Nk - 1);
             breg = key >= a.bias_skip ? lsp[key - a.bias_skip] * LOG2E : 0.0f;
         }
-#if !(ATT_ABL & 2)
         __syncthreads();   // tile t+1 visible; every wave has left iteration t-1
-#endif
         // (measured: a hand-placed issue order of this block -- every MFMA followed by the vector work that fits its
         // shadow, pinned by sched_barrier fences -- runs within 1 % of what the compiler makes of it)
         // the partly filled last tile with at most 32 keys in range: the second half of its scores is never computed
         const bool half = masked && (t + 1) * ATT_BN + 32 >= a.Nk;
         scores(S, negm, half);
         pv();
-#if !(ATT_ABL & 4)
         v_fragments(S);
-#endif
-#if ATT_PRIO == 2
         if (!(BIAS && WAVES == 4)) __builtin_amdgcn_s_setprio(1);  // (that instance would spill: the builtin fences the scheduler)
-#endif
-#if !(ATT_ABL & 1)
 #pragma unroll
         for (int v = 0; v < 16; ++v) s0[v] = __builtin_amdgcn_exp2f(s0[v]);
 #pragma unroll
         for (int v = 0; v < 16; ++v) s1[v] = __builtin_amdgcn_exp2f(s1[v]);
-#endif
         if (masked) {  // the partly filled last tile: keys past the end weigh nothing
             const int key0 = (t + 1) * ATT_BN + 4 * hf;
 #pragma unroll
@@ -448,9 +432,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void k_prop_attention(AttnArgs a) { 
         }
         const float lsum = att_add(att_add(c0s, c1s), att_add(c2s, c3s));
         pack_p();
-#if ATT_PRIO == 2
         if (!(BIAS && WAVES == 4)) __builtin_amdgcn_s_setprio(0);
-#endif
         l_run += lsum;
         bad = bad || !(lsum <= AttLimit<TX>::value);  // inf / NaN / too large: this pass is void (rerun below)
     };

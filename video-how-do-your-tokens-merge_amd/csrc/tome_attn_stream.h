@@ -39,11 +39,6 @@
 #endif
 
 #define ATS_BIAS_GROUP 4  // tiles per bias load (power of two; 2 * GROUP * 64 words of LDS)
-#ifdef ATS_ABL
-#define ATS_ABL_BIT(b) ((ATS_ABL & (b)) != 0)
-#else
-#define ATS_ABL_BIT(b) false
-#endif
 template <typename TX, bool BIAS>
 __global__ __launch_bounds__(512, 2) void k_prop_attention_stream(AttnArgs a, int nitems) {
     constexpr int WAVES = 8;
@@ -138,7 +133,7 @@ __global__ __launch_bounds__(512, 2) void k_prop_attention_stream(AttnArgs a, in
         // put ~25 instructions per step on wave 0 alone, and every wave waits for the slowest at the barrier
         // (measured: 10 % of the kernel)
         r_sub = s_t & (ATS_BIAS_GROUP - 1);
-        if (BIAS && r_sub == 0 && tid < ATS_BIAS_GROUP * ATT_BN && !ATS_ABL_BIT(2)) {
+        if (BIAS && r_sub == 0 && tid < ATS_BIAS_GROUP * ATT_BN) {
             const int key = min(s_t * ATT_BN + tid, nk - 1);
             // log2-domain bias as two 16-bit terms hi + lo (what is left is below 2^-15 of the bias for bf16)
             const float bv = key >= bias_skip ? s_ls[key - bias_skip] * LOG2E : 0.0f;
@@ -263,7 +258,7 @@ __global__ __launch_bounds__(512, 2) void k_prop_attention_stream(AttnArgs a, in
         const short *ks0 = kbase + S * ATT_BN * ATT_KS;
         s0 = cinit;
         s1 = cinit;
-        if (BIAS && !ATS_ABL_BIT(4)) bias_step(S);
+        if (BIAS) bias_step(S);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks)
             s0 = AttMfma<TX>::run(*reinterpret_cast<const att_s16x8 *>(ks0 + 16 * ks), qf[ks], s0);
@@ -385,9 +380,7 @@ __global__ __launch_bounds__(512, 2) void k_prop_attention_stream(AttnArgs a, in
         }
 #endif
         stream_load();
-#if !defined(ATS_ABL) || !(ATS_ABL & 1)
-        __syncthreads();  // (ATS_ABL & 1: measurement build without it -- results wrong by design)
-#endif
+        __syncthreads();
 #ifdef ATT_DIAG
         if (diag_n == 2) {
             d2_ = __builtin_amdgcn_s_memrealtime();
@@ -398,9 +391,7 @@ __global__ __launch_bounds__(512, 2) void k_prop_attention_stream(AttnArgs a, in
         scores(S, negm, masked && last_half);
         pv(false);
         v_fragments(S);
-#if ATT_PRIO == 2
         __builtin_amdgcn_s_setprio(1);
-#endif
 #pragma unroll
         for (int v = 0; v < 16; ++v) s0[v] = __builtin_amdgcn_exp2f(s0[v]);
 #pragma unroll
@@ -428,9 +419,7 @@ __global__ __launch_bounds__(512, 2) void k_prop_attention_stream(AttnArgs a, in
         }
         const float lsum = att_add(att_add(c0s, c1s), att_add(c2s, c3s));
         pack_p();
-#if ATT_PRIO == 2
         __builtin_amdgcn_s_setprio(0);
-#endif
         const float l_before = l_run;
         l_run += lsum;
         // Overflow guard, at the very end of the step (a branch in the middle of it keeps the compiler from
