@@ -21,11 +21,14 @@
 #pragma once
 
 #define RES_ROWS 224  // K / V rows resident per workgroup: 3 full 64-key tiles + the first half of a fourth
+#ifndef RES_VS
+#define RES_VS ATT_VS  // V row stride in LDS (elements)
+#endif
 
 template <typename TX, bool BIAS>
 __global__ __launch_bounds__(512, 4) void k_resident_attention(AttnArgs a) {
     __shared__ __attribute__((aligned(16))) short lds_k[RES_ROWS * ATT_KS];  // 32256 B
-    __shared__ __attribute__((aligned(16))) short lds_v[RES_ROWS * ATT_VS];  // 43008 B
+    __shared__ __attribute__((aligned(16))) short lds_v[RES_ROWS * RES_VS];  // 43008 B
     // A FIFTH k-step carries what would otherwise be vector work on 16 accumulator registers per block:
     //   channels 2, 3: K side 1, Q side -m_ref split into two terms hi + lo of the 16-bit format (residual < 2^-15 |m|:
     //              a common factor of at most 2^(1e-4) between the first block's weights and the later ones, far below
@@ -38,6 +41,7 @@ __global__ __launch_bounds__(512, 4) void k_resident_attention(AttnArgs a) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int col = lane & 31, hf = lane >> 5;
+    ATT_STAMP(0);  // entry (diagnostic build only: tools/attn_diag.py)
     // XCD-aware item numbering: the nseg segments of one (batch, head) read the same Q rows -> same XCD (workgroup L
     // runs on XCD L % 8), one after the other
     const int L = blockIdx.x;
@@ -83,7 +87,7 @@ __global__ __launch_bounds__(512, 4) void k_resident_attention(AttnArgs a) {
             const int idx = tid + 512 * i, key = idx >> 3, c = idx & 7;
             if (idx < NCH) {
                 *reinterpret_cast<uint4 *>(lds_k + key * ATT_KS + 8 * c) = kr[i];
-                *reinterpret_cast<uint4 *>(lds_v + key * ATT_VS + 8 * c) = vr[i];
+                *reinterpret_cast<uint4 *>(lds_v + key * RES_VS + 8 * c) = vr[i];
             }
         }
         if (BIAS && tid < RES_ROWS) {
@@ -97,11 +101,13 @@ __global__ __launch_bounds__(512, 4) void k_resident_attention(AttnArgs a) {
             *reinterpret_cast<att_s16x8 *>(lds_kb + tid * 8) = row;
         }
     }
+    ATT_STAMP(1);  // staging loads consumed, LDS written
     __syncthreads();  // the only barrier: from here on the waves are on their own
+    ATT_STAMP(2);  // K / V resident
 
     typedef __attribute__((address_space(3))) att_s16x4 *lds_s16x4_p;
     const short *const kbase = lds_k + col * ATT_KS + 8 * hf;
-    const short *const vbase = lds_v + (4 * hf + ((lane & 15) >> 2)) * ATT_VS + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+    const short *const vbase = lds_v + (4 * hf + ((lane & 15) >> 2)) * RES_VS + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
     const float sl = a.scale * LOG2E;
 
     for (int qt = wave; qt < ntq; qt += 8) {
@@ -120,6 +126,7 @@ __global__ __launch_bounds__(512, 4) void k_resident_attention(AttnArgs a) {
         for (int e = 0; e < 8; ++e) qx[e] = kone[e] = 0;
         kone[2] = kone[3] = att_bits<TX>(1.0f);
         if (BIAS && hf == 0) qx[0] = qx[1] = att_bits<TX>(bfac);
+        ATT_STAMP(3);  // Q~ in registers
         att_s16x8 qf[4];  // q * scale * log2(e), rounded once to the 16-bit format
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
@@ -161,11 +168,11 @@ __global__ __launch_bounds__(512, 4) void k_resident_attention(AttnArgs a) {
         auto pv = [&](int blk) __attribute__((always_inline)) {
 #pragma unroll
             for (int p = 0; p < 2; ++p) {
-                const short *va = vbase + (blk * 32 + 16 * p) * ATT_VS;
+                const short *va = vbase + (blk * 32 + 16 * p) * RES_VS;
                 const att_s16x4 f0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(va));
-                const att_s16x4 f1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(va + 8 * ATT_VS));
+                const att_s16x4 f1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(va + 8 * RES_VS));
                 const att_s16x4 f2 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(va + 32));
-                const att_s16x4 f3 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(va + 8 * ATT_VS + 32));
+                const att_s16x4 f3 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(va + 8 * RES_VS + 32));
                 att_s16x8 vf0, vf1;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -249,6 +256,7 @@ __global__ __launch_bounds__(512, 4) void k_resident_attention(AttnArgs a) {
             bad = bad || !(lsum <= AttLimit<TX>::value);  // inf / NaN / too large: this pass is void
         }
         pv(last_blk);
+        ATT_STAMP(4);  // block loop done
         // ---- the guard tripped in this wave (weights beyond the 16-bit format's range: the reference point fixed by the
         // first block lagged the scores -- adversarial inputs): the query tile again, reference following the maximum
         if (__ballot(bad)) {
@@ -283,6 +291,7 @@ __global__ __launch_bounds__(512, 4) void k_resident_attention(AttnArgs a) {
             const uint4 row16 = uint4{s0w[0], s1w[0], s0w[1], s1w[1]};
             if (qrow < a.N) *reinterpret_cast<uint4 *>(op + 8 * g) = row16;
         }
+        ATT_STAMP(5);  // this tile's stores issued
         if (qt + 8 < ntq) {  // the next tile's rows (wave-uniform); the other waves of the SIMD cover their latency
             const int qload = min((qt + 8) * 32 + col, a.N - 1);
 #pragma unroll
