@@ -110,15 +110,16 @@ __global__ __launch_bounds__(256) void k_unit_rows_f(const bf16_t *__restrict__ 
         if (l < nblk) ss = __fadd_rn(ss, p);  // blocks in ascending order, as k_unit_rows
     }
     const float nr = __builtin_sqrtf(ss);
-    // would the unit vector hold a NaN?  (merge.py:51 has no epsilon: a zero / inf / NaN token) -- decided on the
-    // divisions the contract would make
+    // would the unit vector hold a NaN?  (merge.py:51 has no epsilon: a zero / inf / NaN token.)  The contract's
+    // division v / ||v|| is a NaN exactly when an operand is one, or both are zero, or both are infinite (IEEE 754) --
+    // decided from the operands: the eight correctly rounded divisions per lane this replaced were a fifth of the
+    // kernel's vector instructions, and only their NaN-ness was used
     bool nan_here = false;
     if (in_range) {
+        const bool n_nan = nr != nr, n_zero = nr == 0.0f, n_inf = __builtin_isinf(nr);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const float u = __fdiv_rn(v[e], nr);
-            nan_here = nan_here || (u != u);
-        }
+        for (int e = 0; e < 8; ++e)
+            nan_here = nan_here || (v[e] != v[e]) || n_nan || (n_zero && v[e] == 0.0f) || (n_inf && __builtin_isinf(v[e]));
     }
     const int rowi = t >> 1;
     const bool odd = t & 1;
@@ -202,7 +203,8 @@ __global__ __launch_bounds__(64) void k_scores_filter(const uint4 *__restrict__ 
     float window[FILT_ATW], thr[FILT_ATW];
     int cnt[FILT_ATW];
     unsigned rec[FILT_ATW][FILT_KH];
-    bool row_ok[FILT_ATW], a_out[FILT_ATW];
+    bool row_ok[FILT_ATW];
+    unsigned a_out = 0u;  // bit u: a row of A tile u has a norm outside the trusted range (wave-uniform: a scalar register)
 #pragma unroll
     for (int u = 0; u < FILT_ATW; ++u) {
         const int ti = min(ti0 + u, ntA - 1);  // (a wave past the last tile repeats it and writes nothing)
@@ -216,7 +218,7 @@ __global__ __launch_bounds__(64) void k_scores_filter(const uint4 *__restrict__ 
         row_ok[u] = (ti0 + u < ntA) && i < T1;
         // the window on the scale of S~ = S * ||v_i||
         const float ni = row_ok[u] ? normA[(int64_t)g * T1 + i] : 1.0f;
-        a_out[u] = !(ni >= FILT_NORM_LO && ni <= FILT_NORM_HI);
+        a_out |= (__ballot(!(ni >= FILT_NORM_LO && ni <= FILT_NORM_HI)) != 0ull) ? (1u << u) : 0u;
         window[u] = FILT_WINDOW * (row_ok[u] ? ni : 0.0f);
         thr[u] = -INFINITY;
         cnt[u] = 0;
@@ -298,8 +300,8 @@ __global__ __launch_bounds__(64) void k_scores_filter(const uint4 *__restrict__ 
         }
         // a lane whose list overflowed (exact ties, monotone columns), or a norm out of range: the tile's rows get the
         // fp32 pass (the fallback waves of the k_exact_rows launch)
-        const unsigned long long ov = __ballot(row_ok[u] && (cnt[u] > FILT_KH || a_out[u]));
-        if (lane == 0) tile_flag[(int64_t)g * ntA + ti] = (ov || force_group) ? 1 : 0;
+        const unsigned long long ov = __ballot(row_ok[u] && cnt[u] > FILT_KH);
+        if (lane == 0) tile_flag[(int64_t)g * ntA + ti] = (ov || force_group || ((a_out >> u) & 1u)) ? 1 : 0;
     }
 }
 
