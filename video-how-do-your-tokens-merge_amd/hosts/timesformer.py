@@ -49,7 +49,7 @@ class Attention(nn.Module):
                 and _abi.short_attention_ok(q, k, v):
             # the temporal attention: thousands of sequences of T <= 8 tokens -- one streaming pass over q, k, v
             # (tome_short_attention: 5 TB/s; the framework's fused attention + the head transpose run at 2.8)
-            x = _abi.short_attention(q, k, v, self.scale)
+            x = _abi.short_attention(q, k, v, self.scale, checked=True)
         else:
             x = F.scaled_dot_product_attention(q, k, v, scale=self.scale).transpose(1, 2).reshape(B, N, C)
         return self.proj_drop(self.proj(x)) if self.with_qkv else x

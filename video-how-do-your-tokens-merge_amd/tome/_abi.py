@@ -616,18 +616,22 @@ def prop_attention_ok(q: torch.Tensor) -> bool:
 
 def prop_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, size: Optional[torch.Tensor], scale: float,
                    bias_skip: bool = False, log_bias: Optional[torch.Tensor] = None,
-                   out: Optional[torch.Tensor] = None) -> torch.Tensor:
+                   out: Optional[torch.Tensor] = None, checked: bool = False) -> torch.Tensor:
     """softmax(q k^T * scale + log(size) on the keys) v for head views q [B, H, N, 64], k / v [B, H, Nk, 64] (any
     strides with contiguous channels: the slices of a qkv buffer are read in place); returns [B, N, H*64].
     `size` is the token size tensor [B, Nk(-1), 1] (its log comes from the merge kernel when that emitted it),
     or `log_bias` an fp32 [B, Nk(-1)] view that already holds the bias, or both None.  bias_skip: the TimeSformer
     form -- key 0 / query 0 unbiased, the bias describes keys 1..N-1.  `out`: a [B, N, H, 64] view (channels
     contiguous) to write into instead of a fresh tensor."""
-    for t, name in ((q, "q"), (k, "k"), (v, "v")):
+    # (checked: the caller has just asked prop_attention_ok about q, k and v -- the patches do, per layer; at the
+    # reference's batch of 8 the forward is bound by host time and the three repeated checks are 7 us of it)
+    for t, name in (() if checked else ((q, "q"), (k, "k"), (v, "v"))):
         require_device(t, f"prop_attention({name})")
-        if not prop_attention_ok(t) or t.dtype != q.dtype or t.device != q.device:
+        if not prop_attention_ok(t):
             raise TomeHipError(f"prop_attention: {name} must be a [B, H, N, 64] 16-bit view with 16-byte aligned rows, "
                                f"got {tuple(t.shape)} {t.dtype} strides {t.stride()}")
+    if k.dtype != q.dtype or v.dtype != q.dtype or k.device != q.device or v.device != q.device:
+        raise TomeHipError("prop_attention: q, k, v must share dtype and device")
     B, H, N, D = q.shape
     if k.shape != v.shape or k.shape[:2] != (B, H):
         raise TomeHipError(f"prop_attention: q {tuple(q.shape)}, k {tuple(k.shape)}, v {tuple(v.shape)} do not match")
@@ -707,12 +711,14 @@ def short_attention_ok(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor) -> boo
             and ok(q) and ok(k) and ok(v))
 
 
-def short_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: float) -> torch.Tensor:
+def short_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: float, checked: bool = False
+                    ) -> torch.Tensor:
     """softmax(q k^T * scale) v over sequences of at most 8 tokens (TimeSformer's temporal attention): q, k, v
-    [B, H, N, 64] views of one qkv projection, read in place; returns [B, N, H*64]."""
-    for t, name in ((q, "q"), (k, "k"), (v, "v")):
+    [B, H, N, 64] views of one qkv projection, read in place; returns [B, N, H*64].  checked: the caller has just
+    asked short_attention_ok."""
+    for t, name in (() if checked else ((q, "q"), (k, "k"), (v, "v"))):
         require_device(t, f"short_attention({name})")
-    if not short_attention_ok(q, k, v):
+    if not checked and not short_attention_ok(q, k, v):
         raise TomeHipError(f"short_attention: q, k, v must be [B, H, N <= 8, 64] 16-bit views with head stride 64 and "
                            f"16-byte aligned rows, got {tuple(q.shape)} {q.dtype} strides {q.stride()}")
     B, H, N, D = q.shape

@@ -192,7 +192,7 @@ def attention(q, k, v, size, scale: float, dropout_p: float = 0.0, bias_skip: bo
     B, H, N, hd = q.shape
     if (_ATTN_KERNEL and dropout_p == 0.0 and _abi.prop_attention_ok(q) and _abi.prop_attention_ok(k)
             and _abi.prop_attention_ok(v)):
-        return _abi.prop_attention(q, k, v, size, scale, bias_skip=bias_skip)
+        return _abi.prop_attention(q, k, v, size, scale, bias_skip=bias_skip, checked=True)
     bias = None
     if size is not None:
         log = _abi.log_of_size(size)[:, None, None, :, 0].to(q.dtype)
