@@ -575,6 +575,10 @@ def worker(args):
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU path in the product)")
     launch.require_one_gpu_per_rank(args.backend, world)  # (RCCL with more ranks than GPUs dies inside the library)
+    if world > 1:
+        # N ranks share the node's host cores: every rank keeps its share for the framework's intra-op pool (the
+        # forward issues from one thread; an N x cores oversubscription only adds scheduling noise to the launch path)
+        torch.set_num_threads(max(1, usable_cpus() // world))
     dev_index = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)

@@ -36,8 +36,9 @@ __global__ __launch_bounds__(512, 4) void k_resident_attention(AttnArgs a) {
     //              s - m_ref (no 16 moves per block, no 16 registers holding the start values);
     //   channels 0, 1 (BIAS): K side the key's log(size) * log2(e) split into two 16-bit terms hi + lo (residual < 2^-15
     //              of the bias for bf16, 2^-21 for fp16), Q side bfac (0 for TimeSformer's unbiased class query, else 1).
-    // BIAS: the K-side fragment of a key is a 16-byte row of lds_kb; plain: one constant register fragment.
-    __shared__ __attribute__((aligned(16))) short lds_kb[BIAS ? RES_ROWS * 8 : 8];  // 3584 B -> 78848 B per workgroup
+    // The K-side fragment of a key is a 16-byte row of lds_kb (plain: bias terms 0) -- a constant register fragment for
+    // the plain form would be four more registers live through the block loop.
+    __shared__ __attribute__((aligned(16))) short lds_kb[RES_ROWS * 8];  // 3584 B -> 78848 B per workgroup
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int col = lane & 31, hf = lane >> 5;
@@ -90,7 +91,7 @@ __global__ __launch_bounds__(512, 4) void k_resident_attention(AttnArgs a) {
                 *reinterpret_cast<uint4 *>(lds_v + key * RES_VS + 8 * c) = vr[i];
             }
         }
-        if (BIAS && tid < RES_ROWS) {
+        if (tid < RES_ROWS) {
             const float hi = to_f32(from_f32<TX>(br));
             att_s16x8 row;
 #pragma unroll
@@ -121,10 +122,9 @@ __global__ __launch_bounds__(512, 4) void k_resident_attention(AttnArgs a) {
         // TimeSformer form (bias_skip): key 0 and query 0 carry no bias -- the class query's lane multiplies it by 0
         const float bfac = (a.bias_skip && qrow == 0) ? 0.0f : 1.0f;
         // Q side of the fifth k-step (see the top of the kernel); the upper lane half multiplies the K side by zeros
-        att_s16x8 qx, kone;
+        att_s16x8 qx;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) qx[e] = kone[e] = 0;
-        kone[2] = kone[3] = att_bits<TX>(1.0f);
+        for (int e = 0; e < 8; ++e) qx[e] = 0;
         if (BIAS && hf == 0) qx[0] = qx[1] = att_bits<TX>(bfac);
         ATT_STAMP(3);  // Q~ in registers
         att_s16x8 qf[4];  // q * scale * log2(e), rounded once to the 16-bit format
@@ -154,8 +154,7 @@ __global__ __launch_bounds__(512, 4) void k_resident_attention(AttnArgs a) {
             const short *kt = kbase + blk * 32 * ATT_KS;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) sc = AttMfma<TX>::run(*reinterpret_cast<const att_s16x8 *>(kt + 16 * ks), qf[ks], sc);
-            if (BIAS) sc = AttMfma<TX>::run(*reinterpret_cast<const att_s16x8 *>(lds_kb + (blk * 32 + col) * 8), qx, sc);
-            else sc = AttMfma<TX>::run(kone, qx, sc);
+            sc = AttMfma<TX>::run(*reinterpret_cast<const att_s16x8 *>(lds_kb + (blk * 32 + col) * 8), qx, sc);
         };
         auto pack_p = [&]() __attribute__((always_inline)) {
 #pragma unroll
