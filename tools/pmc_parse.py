@@ -20,7 +20,7 @@ def load(d):
     for row in csv.DictReader(open(f)):
         name = row["Kernel_Name"]
         key = None
-        for k in ("k_merge_rows", "k_scores_rowmax", "k_scores_filter", "k_exact_rows", "k_units_from_means", "k_unit_rows",
+        for k in ("k_merge_rows", "k_scores_rowmax", "k_scores_filter", "k_exact_rows", "k_unit_rows",
                   "k_unit_rows_heads", "k_unit_rows_f", "k_rank_select", "k_add_ln_rows", "bfloat16_copy_kernel"):
             if k in name:
                 key = k

@@ -152,7 +152,7 @@ struct MatchWs {
     // the filter path (tome_match_filter.h; D <= 64): bf16 means in MFMA fragment order, norms, candidate lists
     uint4 *vA, *vB;
     float *normA, *normB, *invB, *node_max;
-    int *node_idx, *any_flag;
+    int *node_idx;
     CandEntry *cand;
     uint8_t *cand_n, *tile_flag;
     int T2p;
@@ -189,7 +189,6 @@ static MatchWs carve(void *base, int64_t n, int64_t T, int64_t D) {
         w.cand = (CandEntry *)(b + off); off = align_up(off + sizeof(CandEntry) * 2 * FILT_KH * (size_t)(n * T1), 256);
         w.cand_n = (uint8_t *)(b + off); off = align_up(off + 2 * (size_t)(n * T1), 256);
         w.tile_flag = (uint8_t *)(b + off); off = align_up(off + (size_t)(n * w.ntA), 256);
-        w.any_flag = (int *)(b + off); off = align_up(off + 256, 256);
     }
     w.bytes = off;
     return w;
