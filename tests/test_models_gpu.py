@@ -810,6 +810,88 @@ def test_fused_block_equals_unfused_block_bf16(host_name, monkeypatch):
     assert float((o1 - o0).abs().max()) <= 0.05 * max(1.0, float(o0.abs().max()))
 
 
+@pytest.mark.parametrize("host_name", ["videomae", "vivit"])
+def test_matching_beside_the_attention_on_the_side_stream(host_name, monkeypatch):
+    """tome/_overlap.py: a patched attention issues its layer's matching on a second HIP stream behind its qkv GEMM, and
+    the merge waits for it.  Same kernels on the same keys, so the forward is BIT-identical to the one that keeps the
+    matching on the caller's stream -- also when the side stream is held up by a spin kernel in front of every
+    matching (a merge that did not wait would read index tensors nobody has written yet) -- every merging layer's
+    matching did run on the side stream, nothing is left un-joined, and a HIP graph captures the fork and the join.
+    (VideoMAE and ViViT: long sequences, streaming attention kernel.  TimeSformer / Motionformer keep the matching on
+    the caller's stream: measured +-0 at large batches and -15..-20 % at batch 8, where they are bound by the host.)"""
+    tome, H = _hosts()
+    from tome import _abi, _overlap
+    from hosts.graphed import GraphedForward
+    torch.manual_seed(0)
+    if host_name == "videomae":
+        model = H["videomae"].VideoMAE(num_frames=8, img_size=64, patch_size=16, embed_dim=128, depth=4, num_heads=2,
+                                       num_classes=9)
+        patch, frames, layers = tome.patch.videomae, 8, 4
+    else:
+        model = H["vivit"].ViViT(num_classes=9, image_size=64, num_frames=8, hidden_size=128, num_hidden_layers=4,
+                                 num_attention_heads=2, intermediate_size=128)
+        patch, frames, layers = tome.patch.vivit, 8, 4
+    model = model.to(DEV).to(torch.bfloat16).eval()
+    patch(model)
+    model.r = 5
+    clip = torch.rand(3, 3, frames, 64, 64, device=DEV).to(torch.bfloat16)
+    streams = []
+    real = _abi.match_keys
+
+    def spy(*a, **k):
+        streams.append(torch.cuda.current_stream().cuda_stream)
+        return real(*a, **k)
+
+    monkeypatch.setattr(_abi, "match_keys", spy)
+    main = torch.cuda.current_stream().cuda_stream
+    with torch.no_grad():
+        monkeypatch.setattr(_overlap, "ENABLED", False)
+        want = model([clip]).clone()
+        assert streams and set(streams) == {main}
+        n_match = len(streams)
+        assert n_match == layers
+        streams.clear()
+        monkeypatch.setattr(_overlap, "ENABLED", True)
+        got = model([clip]).clone()
+        side = _overlap.side_stream(torch.device(DEV)).cuda_stream
+        assert side != main and streams == [side] * n_match
+        assert not _overlap._open
+        assert torch.equal(got, want)
+        # the side stream held up in front of every matching
+        real_beside = _overlap.match_beside
+
+        def late(metric, ready, info):
+            if ready is not None:
+                with torch.cuda.stream(_overlap.side_stream(metric.keys.device)):
+                    torch.cuda._sleep(20_000_000)  # ~10 ms
+            return real_beside(metric, ready, info)
+
+        from tome.patch import _common
+        monkeypatch.setattr(_common, "match_beside", late)
+        streams.clear()
+        got_late = model([clip]).clone()
+        assert streams == [side] * n_match and torch.equal(got_late, want)
+        monkeypatch.setattr(_common, "match_beside", real_beside)
+        # a block that raises between the fork and the join: the model forward joins on its way out
+        def boom(*a, **k):
+            raise RuntimeError("boom")
+        monkeypatch.setattr(_common, "bipartite_soft_matching", boom)
+        seen_open = []
+        real_join = _overlap.join
+        monkeypatch.setattr(_overlap, "join", lambda dev: (seen_open.append(bool(_overlap._open)), real_join(dev))[1])
+        with pytest.raises(RuntimeError, match="boom"):
+            model([clip])
+        assert seen_open == [True] and not _overlap._open
+        monkeypatch.undo()
+        torch.cuda.synchronize()
+    # captured: the side stream joins the capture through the two events
+    fwd = GraphedForward(model, [clip])
+    other = torch.rand(3, 3, frames, 64, 64, device=DEV).to(torch.bfloat16)
+    with torch.no_grad():
+        want_other = model([other]).clone()
+    assert torch.equal(fwd([other]).clone(), want_other) and torch.equal(fwd([clip]).clone(), want)
+
+
 @pytest.mark.parametrize("host_name", ["videomae", "vivit", "timesformer", "motionformer"])
 def test_attention_kernel_equals_framework_attention_bf16(host_name, monkeypatch):
     """Proportional attention through tome_prop_attention (size bias per key inside the kernel; Motionformer: one

@@ -1,0 +1,106 @@
+"""The block's matching on a second HIP stream, beside the block's attention.
+
+The reference runs a block as `qkv GEMM -> attention -> proj GEMM -> bipartite_soft_matching(k.mean(1)) -> merge`
+(`tome/patch/videomae.py:14-30, 48-77`), one op after the other.  The matching needs nothing but the keys, and those
+exist as soon as the qkv GEMM is done; the attention kernel that follows is bound by the matrix and vector pipes with HBM
+nearly idle and leaves a quarter of the register file free, and the matching's largest kernel (`k_unit_rows_f`: all heads'
+keys once, 28 registers) is bound by HBM.  So a patched attention marks the point behind its qkv GEMM (`keys_ready`),
+issues its attention kernel, and hands the keys to `match_beside`, which runs `tome_match_keys` on a per-device side
+stream behind that mark; `bipartite_soft_matching` finds the plan on the metric (`HeadMeanKeys.early`), makes the
+caller's stream wait for the side stream, and uses it.  Same kernels, same inputs, same plan: nothing about the result
+depends on the stream.  Measured (`tools/probes/overlap_match_attention.py`, `tools/overlap_ab.py`,
+`profiles/r04_overlap_probe.txt`): attention + projection + matching 1544 -> 1447 us at batch 128; whole forward +1.0..1.6 %
+on VideoMAE, +0.8..4.1 % on ViViT.  Not wired into TimeSformer / Motionformer: their resident attention kernel fills the
+register file (nothing runs beside it: +-0 at large batches) and at batch 8 they are bound by the host, where the ~35 us
+of stream and event calls per layer cost 15-20 %.
+
+Why this cannot deadlock where two concurrent forwards do (`tome/patch/_common.py`, "One forward in flight"): only this
+package's matching kernels ever run on the side stream -- no library GEMM -- and none of them waits for another
+workgroup, so at most one persistent Stream-K grid is resident at any time.
+
+Memory: the side stream always starts behind an event of the caller's stream and the caller's stream always waits for
+the side stream before it reads the plan (`join`; the patched model forward joins once more on exit, also when a block
+raised), so every tensor either stream allocates is reused only behind the other's last use of it -- the caching
+allocator's per-stream pools need no `record_stream`.  Under HIP-graph capture the side stream becomes part of the
+capture through the same two events.
+
+`TOME_MATCH_STREAM=0` keeps the matching on the caller's stream (measurement switch)."""
+from __future__ import annotations
+
+import os
+from typing import Dict, Optional
+
+import torch
+
+ENABLED = os.environ.get("TOME_MATCH_STREAM", "1") != "0"
+_side: Dict[int, "torch.cuda.Stream"] = {}
+_open: Dict[int, "torch.cuda.Stream"] = {}  # device index -> side stream with work the main stream has not waited for
+
+
+def _index(device) -> int:
+    return torch.cuda.current_device() if device.index is None else device.index
+
+
+def side_stream(device) -> "torch.cuda.Stream":
+    idx = _index(device)
+    s = _side.get(idx)
+    if s is None:
+        s = _side[idx] = torch.cuda.Stream(device=device)
+    return s
+
+
+def keys_ready(keys: torch.Tensor, info: Optional[dict]):
+    """Between a patched attention's qkv GEMM and its attention kernel: the event on the caller's stream behind which
+    `keys` exist -- or None when this layer's matching stays on the caller's stream (switch off, CPU tensors, no plain
+    merge this layer, keys the kernel cannot read in place)."""
+    if not ENABLED or info is None or not keys.is_cuda or info.get("mode") != "merge":
+        return None
+    r_list = info.get("r")
+    if not isinstance(r_list, list) or not r_list or r_list[0] <= 0:
+        return None
+    from . import _abi
+    tokens = keys.shape[-2]
+    if _abi.effective_r(tokens, r_list[0], info["class_token"], info["distill_token"]) <= 0 \
+            or not _abi.keys_fusable(keys):
+        return None
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream(keys.device))
+    return ev
+
+
+def match_beside(metric, ready, info: dict) -> None:
+    """Run this layer's matching of `metric` (a HeadMeanKeys) on the side stream behind `ready` (from `keys_ready`);
+    the plan is left on the metric for `tome.merge` to pick up."""
+    if ready is None:
+        return
+    from . import _abi
+    dev = metric.keys.device
+    side = side_stream(dev)
+    side.wait_event(ready)
+    r, cls, dist = int(info["r"][0]), bool(info["class_token"]), bool(info["distill_token"])
+    _open[_index(dev)] = side
+    with torch.no_grad(), torch.cuda.stream(side):
+        plan = _abi.match_keys(metric.keys, r, cls, dist, checked=True)
+    metric.early = (r, cls, dist, plan)
+
+
+def join(device) -> None:
+    """The caller's current stream waits for whatever the side stream of `device` still has in flight."""
+    if device.type != "cuda":
+        return
+    side = _open.pop(_index(device), None)
+    if side is not None:
+        torch.cuda.current_stream(device).wait_stream(side)
+
+
+def take(metric, r, class_token, distill_token):
+    """(found, plan) -- the plan `match_beside` left on `metric`, after making the caller's stream wait for it.  A
+    plan made for other arguments is dropped (found False); the wait happens all the same."""
+    early = getattr(metric, "early", None)
+    if early is None:
+        return False, None
+    metric.early = None
+    join(metric.keys.device)
+    if early[:3] == (int(r), bool(class_token), bool(distill_token)):
+        return True, early[3]
+    return False, None

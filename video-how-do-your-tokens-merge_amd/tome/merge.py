@@ -28,7 +28,7 @@ from typing import Callable, Optional, Tuple
 
 import torch
 
-from . import _abi
+from . import _abi, _overlap
 
 
 def do_nothing(x, mode=None):
@@ -46,6 +46,7 @@ class HeadMeanKeys:
         if keys.dim() not in (4, 5):
             raise ValueError(f"HeadMeanKeys: [n,H,T,D] or [outer,inner,H,T,D] expected, got {tuple(keys.shape)}")
         self.keys = keys
+        self.early = None  # (r, class_token, distill_token, plan) of a matching already issued (tome/_overlap.py)
 
     @property
     def shape(self):
@@ -80,6 +81,9 @@ def _scores_for_random(metric: torch.Tensor) -> torch.Tensor:
 def _plan(metric, r, class_token, distill_token, random: bool, **want) -> Optional[_abi.MatchPlan]:
     with torch.no_grad():
         if isinstance(metric, HeadMeanKeys):
+            found, plan = _overlap.take(metric, r, class_token, distill_token)
+            if found and not random and not any(want.values()):
+                return plan  # issued beside the block's attention, on the side stream this stream now waits for
             if not random and _abi.keys_fusable(metric.keys):
                 return _abi.match_keys(metric.keys, r, class_token, distill_token, checked=True, **want)
             metric = metric.materialize()

@@ -12,6 +12,7 @@ from typing import Callable, Dict, Tuple
 
 import torch
 
+from .. import _overlap
 from ..merge import (bipartite_soft_matching, bipartite_soft_matching_drop, bipartite_soft_matching_hybrid,
                      merge_source, merge_wavg)
 from ..utils import parse_r
@@ -177,10 +178,18 @@ def wrap_model_forward(model_wrapper: torch.nn.Module, blocks_of: Callable) -> N
             self._tome_info["source"] = None
             self._tome_info.pop("_prenorm", None)
             self._tome_info.pop("_folded", None)
-            return super(sub, self).forward(*args, **kwdargs)
+            try:
+                return super(sub, self).forward(*args, **kwdargs)
+            finally:
+                if param is not None:
+                    _overlap.join(param.device)  # (a matching on the side stream no block waited for: a raise mid-block)
 
     sub = type("ToMeVisionTransformer", (base,), {"forward": forward, "_tome_tag": "ToMeVisionTransformer"})
     model_wrapper.__class__ = sub
+
+
+keys_ready = _overlap.keys_ready      # the block's matching beside its attention, on a second HIP stream:
+match_beside = _overlap.match_beside  # tome/_overlap.py
 
 
 def attention(q, k, v, size, scale: float, dropout_p: float = 0.0, bias_skip: bool = False):

@@ -50,14 +50,17 @@ def _attention_forward(self, x, size: torch.Tensor = None, head_aggregation: str
     q, k, v = qkv[0], qkv[1], qkv[2]
     # softmax(q*scale @ k^T + log(size)) @ v: q, k, v are read in place from the qkv buffer
     drop_p = self.attn_drop.p if self.training else 0.0
-    out = self.proj_drop(self.proj(C.attention(q, k, v, size, self.scale, drop_p)))
+    info = getattr(self, "_tome_info", None)
+    ready = C.keys_ready(k, info) if head_aggregation == "mean" else None  # the keys exist behind the qkv GEMM
+    out = C.attention(q, k, v, size, self.scale, drop_p)
     if head_aggregation == "mean":
         metric = HeadMeanKeys(k)  # k.mean(1), averaged inside the matching kernel when the layer merges
+        C.match_beside(metric, ready, info)  # ... on the side stream, beside the attention and the projection
     elif head_aggregation == "concat":
         metric = k.transpose(1, 2).reshape(B, N, -1)
     else:
         raise ValueError(f"head_aggregation {head_aggregation!r}")
-    return out, metric
+    return self.proj_drop(self.proj(out)), metric
 
 
 def videomae_merge(metric, x, _tome_info):
@@ -108,4 +111,5 @@ def apply_patch(model_wrapper, trace_source: bool = False, prop_attn: bool = Fal
             module.reduction_function = reduction_function
         elif _is_attention(module):
             C.swizzle(module, "ToMeAttention", {"forward": _attention_forward})
+            module._tome_info = model_wrapper._tome_info  # (the layer's r: its matching starts beside its attention)
     C.link_next_norms(model.blocks, "norm1")

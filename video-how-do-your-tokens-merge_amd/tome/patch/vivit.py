@@ -76,6 +76,8 @@ def _self_attention_forward(self, hidden_states, size=None, head_aggregation="me
     else:
         q, k, v = heads(self.query(hidden_states)), heads(self.key(hidden_states)), heads(self.value(hidden_states))
     probs = None
+    info = getattr(self, "_tome_info", None)
+    ready = C.keys_ready(k, info) if head_aggregation == "mean" else None  # the keys exist behind the projection(s)
     if output_attentions or head_mask is not None:
         scores = torch.matmul(q, k.transpose(-1, -2)) / math.sqrt(hd)
         if size is not None:
@@ -89,6 +91,7 @@ def _self_attention_forward(self, hidden_states, size=None, head_aggregation="me
         ctx = C.attention(q, k, v, size, 1.0 / math.sqrt(hd), drop_p)
     if head_aggregation == "mean":
         metric = HeadMeanKeys(k)  # k.mean(1), averaged inside the matching kernel when the layer merges
+        C.match_beside(metric, ready, info)  # ... on the side stream, beside the attention and the output projection
     elif head_aggregation == "concat":
         metric = k.transpose(1, 2).reshape(B, N, -1)
     else:
@@ -176,4 +179,5 @@ def apply_patch(model_wrapper, trace_source: bool = False, prop_attn: bool = Tru
             C.swizzle(module, "ToMeVivitAttention", {"forward": _attention_forward})
         elif _is_self_attention(module):
             C.swizzle(module, "ToMeVivitSelfAttention", {"forward": _self_attention_forward})
+            module._tome_info = model_wrapper._tome_info  # (the layer's r: its matching starts beside its attention)
     C.link_next_norms(model.encoder.layer, "layernorm_before", tag="ToMeVivitLayer")
