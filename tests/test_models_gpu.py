@@ -839,11 +839,12 @@ def test_matching_beside_the_attention_on_the_side_stream(host_name, monkeypatch
     real = _abi.match_keys
 
     def spy(*a, **k):
-        streams.append(torch.cuda.current_stream().cuda_stream)
+        assert torch.cuda.current_stream().cuda_stream == main  # (never a stream switch on the host)
+        streams.append(k.get("stream") or main)  # the raw handle the launches go to
         return real(*a, **k)
 
-    monkeypatch.setattr(_abi, "match_keys", spy)
     main = torch.cuda.current_stream().cuda_stream
+    monkeypatch.setattr(_abi, "match_keys", spy)
     with torch.no_grad():
         monkeypatch.setattr(_overlap, "ENABLED", False)
         want = model([clip]).clone()
@@ -852,6 +853,10 @@ def test_matching_beside_the_attention_on_the_side_stream(host_name, monkeypatch
         assert n_match == layers
         streams.clear()
         monkeypatch.setattr(_overlap, "ENABLED", True)
+        model([clip])
+        assert set(streams) == {main} and len(streams) == n_match  # too small a forward to fork in eager mode ...
+        streams.clear()
+        monkeypatch.setattr(_overlap, "MIN_WORK", 0)
         got = model([clip]).clone()
         side = _overlap.side_stream(torch.device(DEV)).cuda_stream
         assert side != main and streams == [side] * n_match
@@ -884,8 +889,13 @@ def test_matching_beside_the_attention_on_the_side_stream(host_name, monkeypatch
         assert seen_open == [True] and not _overlap._open
         monkeypatch.undo()
         torch.cuda.synchronize()
-    # captured: the side stream joins the capture through the two events
-    fwd = GraphedForward(model, [clip])
+    # captured: the side stream joins the capture through the two events (... but always inside a capture)
+    main = torch.cuda.current_stream().cuda_stream
+    seen = []
+    real = _abi.match_keys
+    monkeypatch.setattr(_abi, "match_keys", lambda *a, **k: (seen.append(k.get("stream")), real(*a, **k))[1])
+    fwd = GraphedForward(model, [clip], warmup=1)
+    assert seen[:layers] == [None] * layers and seen[layers:] == [_overlap.side_stream(torch.device(DEV)).cuda_stream] * layers
     other = torch.rand(3, 3, frames, 64, 64, device=DEV).to(torch.bfloat16)
     with torch.no_grad():
         want_other = model([other]).clone()

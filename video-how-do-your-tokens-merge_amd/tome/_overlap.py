@@ -18,13 +18,17 @@ Why this cannot deadlock where two concurrent forwards do (`tome/patch/_common.p
 package's matching kernels ever run on the side stream -- no library GEMM -- and none of them waits for another
 workgroup, so at most one persistent Stream-K grid is resident at any time.
 
-Memory: the side stream always starts behind an event of the caller's stream and the caller's stream always waits for
-the side stream before it reads the plan (`join`; the patched model forward joins once more on exit, also when a block
-raised), so every tensor either stream allocates is reused only behind the other's last use of it -- the caching
-allocator's per-stream pools need no `record_stream`.  Under HIP-graph capture the side stream becomes part of the
-capture through the same two events.
+Memory: the matching is LAUNCHED on the side stream (its raw handle goes to the C ABI) but everything is allocated from
+the caller's stream's pool -- no stream switch on the host, which at the reference's batch of 8 costs more than the
+overlap gains.  The side stream always starts behind an event of the caller's stream, and the caller's stream always
+waits for the side stream (`join`; the patched model forward joins once more on exit, also when a block raised) before
+it reads the plan or lets go of the matching's scratch (`plan.workspace`, dropped in `take`), so every block is reused
+only behind the side stream's last use of it; the keys are held by the metric until then.  Two events per device,
+re-recorded every layer (a wait refers to the record that precedes it).  Under HIP-graph capture the side stream becomes
+part of the capture through the same two events.
 
-`TOME_MATCH_STREAM=0` keeps the matching on the caller's stream (measurement switch)."""
+`TOME_MATCH_STREAM=0` keeps the matching on the caller's stream (measurement switch); `TOME_MATCH_STREAM_MIN` is the
+size from which an eager forward forks (below)."""
 from __future__ import annotations
 
 import os
@@ -33,20 +37,31 @@ from typing import Dict, Optional
 import torch
 
 ENABLED = os.environ.get("TOME_MATCH_STREAM", "1") != "0"
-_side: Dict[int, "torch.cuda.Stream"] = {}
-_open: Dict[int, "torch.cuda.Stream"] = {}  # device index -> side stream with work the main stream has not waited for
+# Eager launches that alternate between two streams cost the host 30-50 us per layer (measured:
+# profiles/r04_overlap_probe.txt, "host issue"); a forward whose device time is close to its host time -- VideoMAE at the
+# reference's batch of 8: 4.7 ms against 3.1-3.9 ms -- gains 2 % on a quiet host and loses 15 % on a busy one.  So the
+# fork needs groups x tokens^2 (what the attention beside it scales with) of at least this, or a HIP-graph capture
+# (no host in the replay): VideoMAE from batch 32, ViViT-3137 from batch 8.
+MIN_WORK = int(float(os.environ.get("TOME_MATCH_STREAM_MIN", "6e7")))
+_side: Dict[int, tuple] = {}  # device index -> (side stream, its raw handle, fork event, join event)
+_open: Dict[int, tuple] = {}  # device index -> the same, while the side stream has work the main stream has not waited for
 
 
 def _index(device) -> int:
     return torch.cuda.current_device() if device.index is None else device.index
 
 
-def side_stream(device) -> "torch.cuda.Stream":
+def _state(device) -> tuple:
     idx = _index(device)
-    s = _side.get(idx)
-    if s is None:
-        s = _side[idx] = torch.cuda.Stream(device=device)
-    return s
+    st = _side.get(idx)
+    if st is None:
+        s = torch.cuda.Stream(device=device)
+        st = _side[idx] = (s, s.cuda_stream, torch.cuda.Event(), torch.cuda.Event())
+    return st
+
+
+def side_stream(device) -> "torch.cuda.Stream":
+    return _state(device)[0]
 
 
 def keys_ready(keys: torch.Tensor, info: Optional[dict]):
@@ -63,7 +78,9 @@ def keys_ready(keys: torch.Tensor, info: Optional[dict]):
     if _abi.effective_r(tokens, r_list[0], info["class_token"], info["distill_token"]) <= 0 \
             or not _abi.keys_fusable(keys):
         return None
-    ev = torch.cuda.Event()
+    if keys.shape[0] * tokens * tokens < MIN_WORK and not torch.cuda.is_current_stream_capturing():
+        return None
+    ev = _state(keys.device)[2]
     ev.record(torch.cuda.current_stream(keys.device))
     return ev
 
@@ -75,12 +92,11 @@ def match_beside(metric, ready, info: dict) -> None:
         return
     from . import _abi
     dev = metric.keys.device
-    side = side_stream(dev)
-    side.wait_event(ready)
+    st = _state(dev)
+    st[0].wait_event(ready)
     r, cls, dist = int(info["r"][0]), bool(info["class_token"]), bool(info["distill_token"])
-    _open[_index(dev)] = side
-    with torch.no_grad(), torch.cuda.stream(side):
-        plan = _abi.match_keys(metric.keys, r, cls, dist, checked=True)
+    _open[_index(dev)] = st
+    plan = _abi.match_keys(metric.keys, r, cls, dist, checked=True, stream=st[1])
     metric.early = (r, cls, dist, plan)
 
 
@@ -88,9 +104,10 @@ def join(device) -> None:
     """The caller's current stream waits for whatever the side stream of `device` still has in flight."""
     if device.type != "cuda":
         return
-    side = _open.pop(_index(device), None)
-    if side is not None:
-        torch.cuda.current_stream(device).wait_stream(side)
+    st = _open.pop(_index(device), None)
+    if st is not None:
+        st[3].record(st[0])
+        torch.cuda.current_stream(device).wait_event(st[3])
 
 
 def take(metric, r, class_token, distill_token):
@@ -101,6 +118,9 @@ def take(metric, r, class_token, distill_token):
         return False, None
     metric.early = None
     join(metric.keys.device)
+    plan = early[3]
+    if plan is not None:
+        plan.workspace = None  # back to the caller's pool, behind the wait
     if early[:3] == (int(r), bool(class_token), bool(distill_token)):
-        return True, early[3]
+        return True, plan
     return False, None
