@@ -39,7 +39,7 @@ enum tome_status {
     TOME_ELAUNCH = 3     /* HIP reported a launch error (text in tome_last_error()) */
 };
 
-#define TOME_ABI_VERSION 8
+#define TOME_ABI_VERSION 9
 
 int tome_abi_version(void);
 
@@ -295,6 +295,17 @@ int tome_unmerge(const void *x, int dtype, int64_t n, int64_t T, int64_t C, int6
  * motionformer.py:29; the models' `act_layer=nn.GELU`): y = x * 0.5 * (1 + erf(x / sqrt(2))) on `elements` 16-bit
  * values (a multiple of 8), fp32 arithmetic, bit-identical to the framework's kernel.  y may alias x. */
 int tome_gelu_erf(const void *x, int dtype, int64_t elements, void *y, tome_stream_t stream);
+
+/* tome_tubelet_rows  <-  the models' patch embedding, a convolution whose stride equals its kernel
+ * (slowfast/models/videomae_video_model_builder.py:137-166 `PatchEmbed.proj`; TimeSformer's per-frame Conv2d; Motionformer
+ * `PatchEmbed3D`; ViViT's tubelet Conv3d): its input side as the [B*N, C*kt*kh*kw] matrix the weight multiplies,
+ *     rows[b, (t', h', w'), (c, dt, dh, dw)] = x[b, c, t'*kt + dt, h'*kh + dh, w'*kw + dw]      (a pure move)
+ * x: any view [B, C, T, H, W] with unit stride along W, x_strides = element strides {b, c, t, h}; elem_bytes 2 or 4;
+ * kw * elem_bytes and every stride a multiple of 16 bytes.  Token order (t', h', w') row-major =
+ * `conv(x).flatten(2).transpose(1, 2)`; inner order = the flattened convolution weight's. */
+int tome_tubelet_rows(const void *x, int elem_bytes, int64_t B, int64_t C, int64_t T, int64_t H, int64_t W,
+                      const int64_t *x_strides, int64_t kt, int64_t kh, int64_t kw, void *rows,
+                      tome_stream_t stream);
 
 /* tome_row_map / tome_source_init  <-  merge_source(merge, x, source=None) (merge.py:372-384) and the drop modes'
  * `drop(eye)` (tome/patch/videomae.py:112-117): the first layer's source matrix.  The reference builds an

@@ -33,6 +33,7 @@
 #include "tome_attn.h"
 #include "tome_attn_stream.h"
 #include "tome_attn_resident.h"
+#include "tome_embed.h"
 
 // ------------------------------------------------------------------------------------------------
 // host side: argument checks, workspace carving, launches
@@ -1081,6 +1082,38 @@ extern "C" int tome_gelu_erf(const void *x, int dtype, int64_t elements, void *y
     else
         hipLaunchKernelGGL(k_gelu_erf<f16_t>, dim3((unsigned)blocks), dim3(256), 0, st, (const f16_t *)x, (f16_t *)y, chunks);
     return check_launch("k_gelu_erf");
+}
+
+extern "C" int tome_tubelet_rows(const void *x, int elem_bytes, int64_t B, int64_t C, int64_t T, int64_t H, int64_t W,
+                                 const int64_t *x_strides, int64_t kt, int64_t kh, int64_t kw, void *rows,
+                                 tome_stream_t stream) {
+    if (!x || !rows || !x_strides || B <= 0 || C <= 0 || T <= 0 || H <= 0 || W <= 0 || kt <= 0 || kh <= 0 || kw <= 0)
+        return fail(TOME_EINVAL, "tome_tubelet_rows: bad shape/pointer");
+    if (elem_bytes != 2 && elem_bytes != 4) return fail(TOME_EINVAL, "tome_tubelet_rows: 2- or 4-byte elements only");
+    if (T % kt || H % kh || W % kw) return fail(TOME_EINVAL, "tome_tubelet_rows: the clip must be whole tubelets");
+    if ((kw * elem_bytes) % 16 || !aligned16(x) || !aligned16(rows))
+        return fail(TOME_EINVAL, "tome_tubelet_rows: runs of kw elements must be whole 16-byte chunks in aligned buffers");
+    for (int i = 0; i < 4; ++i)
+        if (x_strides[i] < 0 || (x_strides[i] * elem_bytes) % 16)
+            return fail(TOME_EINVAL, "tome_tubelet_rows: {b, c, t, h} strides must be non-negative multiples of 16 bytes");
+    TubeArgs a;
+    a.sb = x_strides[0]; a.sc = x_strides[1]; a.st = x_strides[2]; a.sh = x_strides[3];
+    a.nt = (int)(T / kt); a.nh = (int)(H / kh); a.nw = (int)(W / kw);
+    a.kt = (int)kt; a.kh = (int)kh;
+    a.cpr = (int)(kw * elem_bytes / 16);
+    const int64_t chunks = C * kt * kh * a.cpr;
+    if (chunks > 0x7fffffffLL || T / kt > 0x7fffffffLL || H / kh > 0x7fffffffLL || W / kw > 0x7fffffffLL)
+        return fail(TOME_EINVAL, "tome_tubelet_rows: too large");
+    a.chunks = (int)chunks;
+    a.items = B * a.nt * a.nh * chunks;
+    const int64_t blocks = (a.items + 255) / 256;
+    if (blocks > 0x7fffffffLL) return fail(TOME_EINVAL, "tome_tubelet_rows: too large");
+    hipStream_t st = (hipStream_t)stream;
+    if (elem_bytes == 2)
+        hipLaunchKernelGGL(k_tubelet_rows<2>, dim3((unsigned)blocks), dim3(256), 0, st, (const uint8_t *)x, (uint8_t *)rows, a);
+    else
+        hipLaunchKernelGGL(k_tubelet_rows<4>, dim3((unsigned)blocks), dim3(256), 0, st, (const uint8_t *)x, (uint8_t *)rows, a);
+    return check_launch("k_tubelet_rows");
 }
 
 extern "C" int tome_row_map(int64_t n, int64_t T, int64_t r, int distill_token, const int64_t *src_idx,

@@ -9,7 +9,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from ._patchify import patch_tokens, tubelet_tokens  # noqa: F401
+from ._patchify import frame_patch_tokens, patch_tokens, tubelet_tokens  # noqa: F401
 from tome import _abi
 
 _SHORT_KERNEL = os.environ.get("TOME_SHORT_ATTN", "1") != "0"  # 0 = the framework's attention for the temporal stage
@@ -97,7 +97,7 @@ class PatchEmbed(nn.Module):
 
     def forward(self, x):
         B, C, T, H, W = x.shape
-        x = patch_tokens(self.proj, x.transpose(1, 2).reshape(B * T, C, H, W))
+        x = frame_patch_tokens(self.proj, x)
         return x, T, W // self.proj.kernel_size[1]
 
 

@@ -21,10 +21,10 @@ SYMBOLS = (
     "tome_merge_wavg_regrouped_ln", "tome_add_layernorm", "tome_add_layernorm_skip_first", "tome_add_layernorm_regrouped", "tome_prop_attention", "tome_prop_attention_segments", "tome_trajectory_mix", "tome_short_attention", "tome_merge",
     "tome_drop",
     "tome_drop_regrouped",
-    "tome_unmerge", "tome_row_map", "tome_source_init", "tome_gelu_erf",
+    "tome_unmerge", "tome_row_map", "tome_source_init", "tome_gelu_erf", "tome_tubelet_rows",
 )
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 DTYPES = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}
 MODES = {"sum": 0, "mean": 1, "amax": 2, "max": 2, "prod": 3, "amin": 4, "min": 4}
 
@@ -108,6 +108,8 @@ def bind(path: str) -> ctypes.CDLL:
     L.tome_unmerge.argtypes = [vp, i32, i64, i64, i64, i64, vp, vp, vp, vp, vp]
     L.tome_gelu_erf.restype = i32
     L.tome_gelu_erf.argtypes = [vp, i32, i64, vp, vp]
+    L.tome_tubelet_rows.restype = i32
+    L.tome_tubelet_rows.argtypes = [vp, i32, i64, i64, i64, i64, i64, vp, i64, i64, i64, vp, vp]
     L.tome_row_map.restype = i32
     L.tome_row_map.argtypes = [i64, i64, i64, i32, vp, vp, vp, vp, vp]
     L.tome_source_init.restype = i32
@@ -827,6 +829,34 @@ def gelu_erf(x: torch.Tensor, inplace: bool = False) -> torch.Tensor:
         rc = lib().tome_gelu_erf(x.data_ptr(), dtype_code(x, "x"), x.numel(), y.data_ptr(), _stream(x.device))
     _check(rc, "tome_gelu_erf")
     return y
+
+
+def tubelet_rows_ok(x: torch.Tensor, kt: int, kh: int, kw: int) -> bool:
+    """x [B, C, T, H, W] (any view with unit stride along W) can be regrouped by tome_tubelet_rows."""
+    if not (x.is_cuda and x.dim() == 5 and x.dtype in DTYPES and x.numel() > 0 and x.stride(4) == 1
+            and not (torch.is_grad_enabled() and x.requires_grad)):
+        return False
+    es = x.element_size()
+    _, _, T, H, W = x.shape
+    return (T % kt == 0 and H % kh == 0 and W % kw == 0 and (kw * es) % 16 == 0 and x.data_ptr() % 16 == 0
+            and all(s >= 0 and (s * es) % 16 == 0 for s in x.stride()[:4]))
+
+
+def tubelet_rows(x: torch.Tensor, kt: int, kh: int, kw: int) -> torch.Tensor:
+    """rows [B, T'*H'*W', C*kt*kh*kw] of a clip x [B, C, T, H, W]: the matrix a stride == kernel convolution's weight
+    multiplies (tome_tubelet_rows: a pure 16-byte move, token order = conv(x).flatten(2).transpose(1, 2))."""
+    if not tubelet_rows_ok(x, kt, kh, kw):
+        require_device(x, "tubelet_rows(x)")
+        raise TomeHipError(f"tubelet_rows: x {tuple(x.shape)} strides {x.stride()} with tubelets {(kt, kh, kw)} "
+                           "cannot be regrouped in 16-byte chunks")
+    B, C, T, H, W = x.shape
+    rows = torch.empty((B, (T // kt) * (H // kh) * (W // kw), C * kt * kh * kw), dtype=x.dtype, device=x.device)
+    strides = (ctypes.c_int64 * 4)(*x.stride()[:4])
+    with _on_device(x.device):
+        rc = lib().tome_tubelet_rows(x.data_ptr(), x.element_size(), B, C, T, H, W, strides, kt, kh, kw,
+                                     rows.data_ptr(), _stream(x.device))
+    _check(rc, "tome_tubelet_rows")
+    return rows
 
 
 def source_init(plan: MatchPlan, drop: bool = False) -> torch.Tensor:
