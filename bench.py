@@ -496,6 +496,16 @@ def also_workloads(dev, quick: bool = False):
     return out
 
 
+def matching_placement(batch: int, tokens: int) -> str:
+    """Where the timed forward runs the matching launches (tome/_overlap.py decides per layer)."""
+    from tome import _overlap
+    if _overlap.ENABLED and batch * tokens * tokens >= _overlap.MIN_WORK:
+        return ("on a second HIP stream behind the layer's qkv GEMM, beside its attention and projection "
+                "(tome/_overlap.py; profiles/r04_overlap_probe.txt): off the step's critical path -- the stage times "
+                "of this object are standalone launches on an idle device")
+    return "on the forward's stream, between projection and merge"
+
+
 def roofline_of(stats, batch: int):
     """Roofline object of the kernel that takes the most device time per forward."""
     name = max(stats, key=lambda k: stats[k]["ms"])
@@ -741,7 +751,8 @@ def worker(args):
                 "launches": ("k_unit_rows_f, k_scores_filter, k_exact_rows (+ fp32 fallback waves), k_rank_select"
                              if filt else "k_unit_rows_heads, k_scores_rowmax, k_rank_select") + ", k_merge_rows_fast<LN>",
                 "note": "SURVEY 8d bytes of the 12 merge calls / time of all their launches (matching stages timed inside "
-                        "tome_match_keys, the merge kernel inside the forward); call counts: profiles/r04_*kernel_stats*"}
+                        "tome_match_keys, the merge kernel inside the forward); call counts: profiles/r04_*kernel_stats*",
+                "matching_in_forward": matching_placement(B, t0_tokens)}
             with torch.no_grad():
                 out["attention_kernel"] = measure_attention(B, t0_tokens, args.r, dev)
         if world == 1 and not args.no_also:
