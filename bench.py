@@ -753,6 +753,15 @@ def worker(args):
                 "note": "SURVEY 8d bytes of the 12 merge calls / time of all their launches (matching stages timed inside "
                         "tome_match_keys, the merge kernel inside the forward); call counts: profiles/r04_*kernel_stats*",
                 "matching_in_forward": matching_placement(B, t0_tokens)}
+            from tome import _overlap
+            if _overlap.ENABLED and B * t0_tokens * t0_tokens >= _overlap.MIN_WORK:
+                # what the path costs the STEP once the matching runs beside the attention: the merge launches alone
+                # (profiles/r04_videomae_forward_composition.txt: the step is the sum of every kernel but the matching's)
+                crit_ms = stats["k_merge_rows"]["ms"]
+                out["merge_path"]["on_the_critical_path"] = {
+                    "launches": "k_merge_rows_fast<LN>", "ms_per_step": round(crit_ms, 4),
+                    "achieved_8d": round(bytes_8d / (crit_ms / 1e3) / 1e9, 1),
+                    "frac_8d": round(bytes_8d / (crit_ms / 1e3) / 1e9 / HBM_PEAK_GBS, 4)}
             with torch.no_grad():
                 out["attention_kernel"] = measure_attention(B, t0_tokens, args.r, dev)
         if world == 1 and not args.no_also:
