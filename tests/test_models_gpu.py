@@ -189,13 +189,20 @@ def _note_measured(name, **values):
         json.dump(seen, f, indent=1)
 
 
+# Runs of one build are bit-reproducible (three runs in a row, round 4: identical errors), so the factor is head-room
+# for the measurement switches, which move rounding points on purpose (README table; `tools/test_switches.sh` runs
+# this file under each: TOME_FUSE_NEXT=0 / TOME_ATTN_KERNEL=0 reach 1.52x on two TimeSformer fixtures).
+_MEASURED_FACTOR = 1.5 if not any(os.environ.get(k) == "0" for k in os.environ if k.startswith("TOME_")) else 2.0
+
+
 def _logit_tol(name, key, scale, ceiling):
-    """1.5 x the error a run on MI355X measured for this fixture (never below 0.2 % of the largest |logit|: the last
-    bits of the library GEMMs differ between library builds), or `ceiling * scale` while no measurement is stored."""
+    """1.5 x the error a run on MI355X measured for this fixture (2 x under a measurement switch; never below 0.2 % of
+    the largest |logit|: the last bits of the library GEMMs differ between library builds), or `ceiling * scale` while
+    no measurement is stored."""
     m = _measured().get(name, {}).get(key)
     if m is None:
         return ceiling * scale
-    return max(1.5 * m, 2e-3 * scale)
+    return max(_MEASURED_FACTOR * m, 2e-3 * scale)
 
 
 @pytest.mark.parametrize("meta", _HD64, ids=lambda m: m["name"])
@@ -1068,7 +1075,8 @@ def test_second_forward_on_another_stream_is_ordered_not_concurrent(monkeypatch)
         monkeypatch.setattr(_common, "_warned_two_streams", False)
         _common._in_flight.clear()
         with torch.cuda.stream(s1):
-            torch.cuda._sleep(200_000_000)  # ~0.1 s: the first forward is certainly still in flight below
+            torch.cuda._sleep(2_000_000_000)  # ~1 s: the first forward is certainly still in flight below, however
+            # slowly a busy host issues it (0.1 s was not enough on one box in round 4)
             out_a = models[0]([clip])
         with warnings.catch_warnings(record=True) as caught:
             warnings.simplefilter("always")
@@ -1081,7 +1089,7 @@ def test_second_forward_on_another_stream_is_ordered_not_concurrent(monkeypatch)
         monkeypatch.setenv("TOME_ONE_FORWARD", "raise")
         _common._in_flight.clear()
         with torch.cuda.stream(s1):
-            torch.cuda._sleep(200_000_000)
+            torch.cuda._sleep(2_000_000_000)
             models[0]([clip])
         with torch.cuda.stream(s2), pytest.raises(RuntimeError, match="in flight"):
             models[1]([clip])
