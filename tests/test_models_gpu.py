@@ -897,6 +897,7 @@ def test_matching_beside_the_attention_on_the_side_stream(host_name, monkeypatch
         monkeypatch.undo()
         torch.cuda.synchronize()
     # captured: the side stream joins the capture through the two events (... but always inside a capture)
+    monkeypatch.setattr(_overlap, "ENABLED", True)  # (monkeypatch.undo() above restored the environment's setting)
     main = torch.cuda.current_stream().cuda_stream
     seen = []
     real = _abi.match_keys
