@@ -846,8 +846,7 @@ def test_matching_beside_the_attention_on_the_side_stream(host_name, monkeypatch
     real = _abi.match_keys
 
     def spy(*a, **k):
-        assert torch.cuda.current_stream().cuda_stream == main  # (never a stream switch on the host)
-        streams.append(k.get("stream") or main)  # the raw handle the launches go to
+        streams.append(torch.cuda.current_stream().cuda_stream)  # launches AND allocations of the matching go there
         return real(*a, **k)
 
     main = torch.cuda.current_stream().cuda_stream
@@ -901,13 +900,53 @@ def test_matching_beside_the_attention_on_the_side_stream(host_name, monkeypatch
     main = torch.cuda.current_stream().cuda_stream
     seen = []
     real = _abi.match_keys
-    monkeypatch.setattr(_abi, "match_keys", lambda *a, **k: (seen.append(k.get("stream")), real(*a, **k))[1])
+    monkeypatch.setattr(_abi, "match_keys",
+                        lambda *a, **k: (seen.append(torch.cuda.current_stream().cuda_stream), real(*a, **k))[1])
     fwd = GraphedForward(model, [clip], warmup=1)
-    assert seen[:layers] == [None] * layers and seen[layers:] == [_overlap.side_stream(torch.device(DEV)).cuda_stream] * layers
+    side = _overlap.side_stream(torch.device(DEV)).cuda_stream
+    assert side not in seen[:layers] and seen[layers:] == [side] * layers
     other = torch.rand(3, 3, frames, 64, 64, device=DEV).to(torch.bfloat16)
     with torch.no_grad():
         want_other = model([other]).clone()
     assert torch.equal(fwd([other]).clone(), want_other) and torch.equal(fwd([clip]).clone(), want)
+
+
+def test_side_stream_matching_shares_no_memory_with_kernels_in_flight(monkeypatch):
+    """The matching beside the attention must take its plan and scratch from the SIDE stream's allocator pool.  Taken
+    from the main stream's pool (round 4's first lean form: launches by raw stream handle) they can be blocks a kernel
+    still in flight on the main stream reads -- the attention wrapper's log(size) temporary, released a microsecond
+    before -- and the matching writes into them beside that reader.  Seen on exactly this case: full-size TimeSformer,
+    64 clips (512 groups: the filter path), prop_attn, the fork forced in eager mode -- the attention output of block
+    4 changed.  The forward with the fork must equal the forward without it bit for bit, twice."""
+    tome, H = _hosts()
+    from tome import _overlap
+    from tome.patch import _common
+    torch.manual_seed(0)
+    model = H["timesformer"].timesformer_base(8).to(DEV).to(torch.bfloat16).eval()
+    tome.patch.timesformer(model)
+    model.r = 16
+    clip = [torch.rand(64, 3, 8, 224, 224, device=DEV).to(torch.bfloat16)]
+    real_ready = _overlap.keys_ready
+    forks = []
+
+    def ready(keys, info, capture_only=False):
+        ev = real_ready(keys, info, False)  # fork in eager mode too
+        forks.append(ev is not None)
+        return ev
+
+    monkeypatch.setattr(_common, "keys_ready", ready)
+    monkeypatch.setattr(_overlap, "MIN_WORK", 0)
+    with torch.no_grad():
+        monkeypatch.setattr(_overlap, "ENABLED", False)
+        want = model(clip).clone()
+        assert not any(forks)
+        monkeypatch.setattr(_overlap, "ENABLED", True)
+        for _ in range(2):
+            forks.clear()
+            got = model(clip).clone()
+            assert all(forks) and len(forks) == 12
+            assert torch.equal(got, want), float((got.float() - want.float()).abs().max())
+    torch.cuda.synchronize()
 
 
 @pytest.mark.parametrize("host_name", ["videomae", "vivit", "timesformer", "motionformer"])

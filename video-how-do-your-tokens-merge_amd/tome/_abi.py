@@ -190,7 +190,7 @@ class MatchPlan:
     row_map for source tracking)."""
 
     __slots__ = ("n", "T", "r", "class_token", "distill_token", "src_idx", "dst_idx", "unm_idx", "node_max",
-                 "row_map", "edge_keep", "device", "workspace")
+                 "row_map", "edge_keep", "device")
 
     def __init__(self, n, T, r, class_token, distill_token, src_idx, dst_idx, unm_idx, node_max, row_map, device):
         self.n, self.T, self.r = n, T, r
@@ -199,7 +199,6 @@ class MatchPlan:
         self.node_max, self.row_map = node_max, row_map
         self.edge_keep = None
         self.device = device
-        self.workspace = None  # scratch of a matching issued on another stream than the allocating one (tome/_overlap.py)
 
 
 def _alloc_plan(n, T, re, class_token, distill_token, device, want_node_max, want_row_map):
@@ -256,12 +255,9 @@ def keys_fusable(keys: torch.Tensor) -> bool:
 
 
 def match_keys(keys: torch.Tensor, r: int, class_token=False, distill_token=False, want_node_max=False,
-               want_row_map=False, checked: bool = False, stream: Optional[int] = None) -> Optional[MatchPlan]:
+               want_row_map=False, checked: bool = False) -> Optional[MatchPlan]:
     """tome_match_keys on per-head keys [n,H,T,64] or [outer,inner,H,T,64] (group = outer*inner + inner index;
-    the metric = keys.mean(heads) is never materialised).
-    stream: raw handle of another HIP stream than the caller's current one to launch on (tome/_overlap.py).  Plan and
-    scratch then still come from the CURRENT stream's pool, so the scratch stays on the plan (`plan.workspace`) until
-    the caller has made the current stream wait for `stream` and drops it."""
+    the metric = keys.mean(heads) is never materialised)."""
     if not checked and not keys_fusable(keys):
         require_device(keys, "match_keys(keys)")
         raise TomeHipError(f"match_keys: keys {tuple(keys.shape)} strides {keys.stride()} are not readable in place")
@@ -279,12 +275,10 @@ def match_keys(keys: torch.Tensor, r: int, class_token=False, distill_token=Fals
     L = lib()
     dev = keys.device
     with _on_device(dev):
-        st = _stream(dev) if stream is None else stream
+        st = _stream(dev)
         nbytes = L.tome_match_workspace_bytes(n, T, D)
         ws = _workspace(dev, st, nbytes)
         plan = _alloc_plan(n, T, re, class_token, distill_token, dev, want_node_max, want_row_map)
-        if stream is not None:
-            plan.workspace = ws
         rc = L.tome_match_keys(keys.data_ptr(), DTYPES[keys.dtype], n, H, T, D, s_n, inner, s_in, s_h, s_t, int(r),
                                int(bool(class_token)), int(bool(distill_token)),
                                plan.src_idx.data_ptr(), plan.dst_idx.data_ptr(), plan.unm_idx.data_ptr(),

@@ -10,22 +10,25 @@ stream behind that mark; `bipartite_soft_matching` finds the plan on the metric 
 caller's stream wait for the side stream, and uses it.  Same kernels, same inputs, same plan: nothing about the result
 depends on the stream.  Measured (`tools/probes/overlap_match_attention.py`, `tools/overlap_ab.py`,
 `profiles/r04_overlap_probe.txt`): attention + projection + matching 1544 -> 1447 us at batch 128; whole forward +1.0..1.6 %
-on VideoMAE, +0.8..4.1 % on ViViT.  Not wired into TimeSformer / Motionformer: their resident attention kernel fills the
-register file (nothing runs beside it: +-0 at large batches) and at batch 8 they are bound by the host, where the ~35 us
-of stream and event calls per layer cost 15-20 %.
+on VideoMAE, +0.8..4.1 % on ViViT.  TimeSformer / Motionformer fork only inside a HIP-graph capture (+0.3..1.3 %): their resident
+attention kernel fills the register file (nothing runs beside it: +-0 for eager forwards at large batches) and at batch 8
+they are bound by the host, where the stream and event calls of a fork cost 15-20 %.
 
 Why this cannot deadlock where two concurrent forwards do (`tome/patch/_common.py`, "One forward in flight"): only this
 package's matching kernels ever run on the side stream -- no library GEMM -- and none of them waits for another
 workgroup, so at most one persistent Stream-K grid is resident at any time.
 
-Memory: the matching is LAUNCHED on the side stream (its raw handle goes to the C ABI) but everything is allocated from
-the caller's stream's pool -- no stream switch on the host, which at the reference's batch of 8 costs more than the
-overlap gains.  The side stream always starts behind an event of the caller's stream, and the caller's stream always
-waits for the side stream (`join`; the patched model forward joins once more on exit, also when a block raised) before
-it reads the plan or lets go of the matching's scratch (`plan.workspace`, dropped in `take`), so every block is reused
-only behind the side stream's last use of it; the keys are held by the metric until then.  Two events per device,
-re-recorded every layer (a wait refers to the record that precedes it).  Under HIP-graph capture the side stream becomes
-part of the capture through the same two events.
+Memory: plan and scratch are allocated while the side stream is the CURRENT stream, i.e. from the caching allocator's
+pool of that stream.  A block of that pool has only ever been touched by side-stream work and by the main stream's
+reads of a plan -- and the side stream always starts behind an event of the main stream recorded after those reads,
+while the main stream always waits for the side stream (`join`; the patched model forward joins once more on exit, also
+when a block raised) before it reads the plan; the keys are held by the metric until then.  (Round 4 tried the cheaper
+form -- launch on the side stream by raw handle, allocate from the MAIN stream's pool: wrong.  That pool hands out blocks
+whose last main-stream reader may still be running -- a temporary the attention wrapper released a microsecond earlier
+-- and the matching then writes into them beside that reader: TimeSformer's attention output changed at batch 64,
+`tools/probes/overlap_diverge.py`; `test_side_stream_matching_shares_no_memory_with_kernels_in_flight` holds the line.)
+Two events per device, re-recorded every layer (a wait refers to the record that precedes it).  Under HIP-graph capture
+the side stream becomes part of the capture through the same two events.
 
 `TOME_MATCH_STREAM=0` keeps the matching on the caller's stream (measurement switch); `TOME_MATCH_STREAM_MIN` is the
 size from which an eager forward forks (below)."""
@@ -64,11 +67,14 @@ def side_stream(device) -> "torch.cuda.Stream":
     return _state(device)[0]
 
 
-def keys_ready(keys: torch.Tensor, info: Optional[dict]):
+def keys_ready(keys: torch.Tensor, info: Optional[dict], capture_only: bool = False):
     """Between a patched attention's qkv GEMM and its attention kernel: the event on the caller's stream behind which
     `keys` exist -- or None when this layer's matching stays on the caller's stream (switch off, CPU tensors, no plain
-    merge this layer, keys the kernel cannot read in place)."""
+    merge this layer, keys the kernel cannot read in place).  capture_only: fork only inside a HIP-graph capture
+    (TimeSformer / Motionformer: an eager fork gains nothing at large batches and costs the host at small ones)."""
     if not ENABLED or info is None or not keys.is_cuda or info.get("mode") != "merge":
+        return None
+    if capture_only and not torch.cuda.is_current_stream_capturing():
         return None
     r_list = info.get("r")
     if not isinstance(r_list, list) or not r_list or r_list[0] <= 0:
@@ -96,7 +102,8 @@ def match_beside(metric, ready, info: dict) -> None:
     st[0].wait_event(ready)
     r, cls, dist = int(info["r"][0]), bool(info["class_token"]), bool(info["distill_token"])
     _open[_index(dev)] = st
-    plan = _abi.match_keys(metric.keys, r, cls, dist, checked=True, stream=st[1])
+    with torch.cuda.stream(st[0]):  # launches AND allocations on the side stream (see "Memory" above)
+        plan = _abi.match_keys(metric.keys, r, cls, dist, checked=True)
     metric.early = (r, cls, dist, plan)
 
 
@@ -118,9 +125,6 @@ def take(metric, r, class_token, distill_token):
         return False, None
     metric.early = None
     join(metric.keys.device)
-    plan = early[3]
-    if plan is not None:
-        plan.workspace = None  # back to the caller's pool, behind the wait
     if early[:3] == (int(r), bool(class_token), bool(distill_token)):
-        return True, plan
+        return True, early[3]
     return False, None

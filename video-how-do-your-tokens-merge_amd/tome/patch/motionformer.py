@@ -51,6 +51,12 @@ def _trajectory_forward(self, x, seq_len=196, num_frames=8, approx="none", num_l
     qkv = self.qkv(x)
     hd = qkv.shape[-1] // (3 * h)
     heads = qkv.view(B, N, 3, h, hd).permute(2, 0, 3, 1, 4)  # q, k, v as [B, h, N, hd] views of the projection
+    # metric = rearrange(k_, '(b h) (s f) d -> (b f) h s d').mean(1) (motionformer.py:143-144): the regrouped keys
+    # are a strided view of the qkv buffer -- [b, f, h, s, d] with token 1 + s*F + f -- and the head mean is taken
+    # inside the matching kernel (tome_match_keys with inner groups), never as a tensor
+    metric = HeadMeanKeys(heads[1][:, :, 1:1 + P * F, :].unflatten(2, (P, F)).permute(0, 3, 1, 2, 4))
+    info = getattr(self, "_tome_info", None)
+    ready = C.keys_ready(metric.keys, info, capture_only=True)  # the keys exist behind the qkv GEMM
     fused = (C._ATTN_KERNEL and not (self.training and self.attn_drop.p > 0.0) and all(_abi.prop_attention_ok(t) for t in heads))
     # flat per-key bias in the reference's '(s f)' order (motionformer.py:107-111): key j of the (f n)-ordered
     # sequence gets log(size) of (s = j // F, f = j % F)
@@ -83,6 +89,7 @@ def _trajectory_forward(self, x, seq_len=196, num_frames=8, approx="none", num_l
         v_ = rearrange(v_, "b (f n) d -> b f n d", f=F, n=P)
         y = torch.einsum("b q f n, b f n d -> b q f d", attn, v_)
         y = rearrange(y, "(b h) s f d -> b s f (h d)", b=B)
+    C.match_beside(metric, ready, info)  # inside a graph capture: the matching on the side stream, beside the temporal stage
     y_diag = rearrange(y, "b (g n) f d -> b g n f d", g=F)
     y_diag = torch.diagonal(y_diag, dim1=-4, dim2=-2)
     y_diag = rearrange(y_diag, "b n d f -> b (f n) d", f=F)
@@ -118,11 +125,7 @@ def _trajectory_forward(self, x, seq_len=196, num_frames=8, approx="none", num_l
         out = rearrange((val * tattn.unsqueeze(-1)).sum(dim=-2), "b h s d -> b s (h d)")  # same remark
         out = torch.cat((cls_out.reshape(B, 1, -1), out), dim=1)
     out = self.proj_drop(self.proj(out))
-    # metric = rearrange(k_, '(b h) (s f) d -> (b f) h s d').mean(1) (motionformer.py:143-144): the regrouped keys
-    # are a strided view of the qkv buffer -- [b, f, h, s, d] with token 1 + s*F + f -- and the head mean is taken
-    # inside the matching kernel (tome_match_keys with inner groups), never as a tensor
-    kview = heads[1][:, :, 1:1 + P * F, :].unflatten(2, (P, F)).permute(0, 3, 1, 2, 4)
-    return out, tattn, HeadMeanKeys(kview)
+    return out, tattn, metric
 
 
 def _regroup(x, num_frames):
@@ -184,4 +187,5 @@ def apply_patch(model, trace_source: bool = False, prop_attn: bool = True, mode:
             module.reduction_function = reduction_function
         elif _is_trajectory_attention(module):
             C.swizzle(module, "ToMeTrajectoryAttention", {"forward": _trajectory_forward})
+            module._tome_info = model._tome_info  # (the layer's r: its matching may start beside its attention)
     C.link_next_norms(model.blocks, "norm1")

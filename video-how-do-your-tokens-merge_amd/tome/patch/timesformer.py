@@ -75,10 +75,14 @@ def _attention_forward(self, x, size: torch.Tensor = None):
         q = k = v = x.reshape(B, N, self.num_heads, Cc // self.num_heads).permute(0, 2, 1, 3)
     # the size bias sits on the non-class block of the logits only (timesformer.py:73-74): bias_skip
     drop_p = self.attn_drop.p if self.training else 0.0
+    info = getattr(self, "_tome_info", None)
+    metric = HeadMeanKeys(k[:, :, 1:, :])  # k.mean(1)[:, 1:, :] averaged inside the matching kernel
+    ready = C.keys_ready(metric.keys, info, capture_only=True)  # the keys exist behind the qkv GEMM
     out = C.attention(q, k, v, size, self.scale, drop_p, bias_skip=True)
+    C.match_beside(metric, ready, info)  # inside a graph capture: the matching on the side stream, beside the attention
     if self.with_qkv:
         out = self.proj_drop(self.proj(out))
-    return out, HeadMeanKeys(k[:, :, 1:, :])  # k.mean(1)[:, 1:, :] averaged inside the matching kernel
+    return out, metric
 
 
 def _regroup(x, B, T, P):
@@ -140,6 +144,7 @@ def apply_patch(model_wrapper, trace_source: bool = False, prop_attn: bool = Tru
             module._tome_info = model_wrapper._tome_info
             module.reduction_function = reduction_function
             C.swizzle(module.attn, "ToMeAttention", {"forward": _attention_forward})
+            module.attn._tome_info = model_wrapper._tome_info  # (the layer's r: its matching may start beside its attention)
     if getattr(model, "attention_type", "divided_space_time") == "divided_space_time":
         # the first LayerNorm of a divided space-time block is temporal_norm1: the previous block's last residual
         # add hands it over fused (tome_add_layernorm)
