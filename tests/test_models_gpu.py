@@ -911,6 +911,49 @@ def test_matching_beside_the_attention_on_the_side_stream(host_name, monkeypatch
     assert torch.equal(fwd([other]).clone(), want_other) and torch.equal(fwd([clip]).clone(), want)
 
 
+@pytest.mark.parametrize("host_name,batch,r", [("videomae", 16, 16), ("timesformer", 64, 16), ("motionformer", 16, 16),
+                                               ("vivit", 4, 64)])
+def test_forward_reads_no_memory_it_did_not_write(host_name, batch, r):
+    """Every kernel of this package takes its buffers from `torch.empty`: nothing may be read before it is written.
+    The caching allocator's pool is pre-filled with a byte pattern (one big tensor filled and released: every later
+    allocation of the forward is carved out of it); the full-size bf16 forward -- filter path of the matching at
+    TimeSformer's 512 groups, the side-stream fork where it applies -- must not depend on the pattern, plans included."""
+    tome, H = _hosts()
+    from tome import _abi
+    torch.manual_seed(0)
+    build, patch, frames, kw = {
+        "videomae": (lambda: H["videomae"].videomae_base(16), tome.patch.videomae, 16, {"prop_attn": False}),
+        "timesformer": (lambda: H["timesformer"].timesformer_base(8), tome.patch.timesformer, 8, {}),
+        "motionformer": (lambda: H["motionformer"].motionformer_base(), tome.patch.motionformer, 16, {}),
+        "vivit": (lambda: H["vivit"].vivit_base(32), tome.patch.vivit, 32, {}),
+    }[host_name]
+    model = build().to(DEV).to(torch.bfloat16).eval()
+    patch(model, **kw)
+    model.r = r
+    clip = [torch.rand(batch, 3, frames, 224, 224, device=DEV).to(torch.bfloat16)]
+    with torch.no_grad():
+        model(clip)
+    torch.cuda.synchronize()
+    peak = torch.cuda.max_memory_allocated()
+    runs = []
+    for fill in (0, 255, "rand"):
+        torch.cuda.empty_cache()
+        junk = torch.empty(int(peak * 1.2), dtype=torch.uint8, device=DEV)
+        junk.random_(0, 256) if fill == "rand" else junk.fill_(fill)
+        torch.cuda.synchronize()
+        del junk
+        with torch.no_grad():
+            out, plans = _trace(tome, model, clip[0], r)
+        runs.append((out.clone(), [(p.src_idx.clone(), p.dst_idx.clone(), p.unm_idx.clone()) for _, p in plans]))
+    torch.cuda.synchronize()
+    for out, plans in runs[1:]:
+        assert not out.isnan().any()
+        assert all(torch.equal(a, b) for pa, pb in zip(plans, runs[0][1]) for a, b in zip(pa, pb))
+        assert torch.equal(out, runs[0][0])
+    del model, clip, runs
+    torch.cuda.empty_cache()
+
+
 def test_side_stream_matching_shares_no_memory_with_kernels_in_flight(monkeypatch):
     """The matching beside the attention must take its plan and scratch from the SIDE stream's allocator pool.  Taken
     from the main stream's pool (round 4's first lean form: launches by raw stream handle) they can be blocks a kernel
