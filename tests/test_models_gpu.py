@@ -954,21 +954,29 @@ def test_forward_reads_no_memory_it_did_not_write(host_name, batch, r):
     torch.cuda.empty_cache()
 
 
-def test_side_stream_matching_shares_no_memory_with_kernels_in_flight(monkeypatch):
+@pytest.mark.parametrize("host_name,batch", [("timesformer", 64), ("videomae", 32)])
+def test_side_stream_matching_shares_no_memory_with_kernels_in_flight(host_name, batch, monkeypatch):
     """The matching beside the attention must take its plan and scratch from the SIDE stream's allocator pool.  Taken
     from the main stream's pool (round 4's first lean form: launches by raw stream handle) they can be blocks a kernel
     still in flight on the main stream reads -- the attention wrapper's log(size) temporary, released a microsecond
     before -- and the matching writes into them beside that reader.  Seen on exactly this case: full-size TimeSformer,
     64 clips (512 groups: the filter path), prop_attn, the fork forced in eager mode -- the attention output of block
-    4 changed.  The forward with the fork must equal the forward without it bit for bit, twice."""
+    4 changed.  The forward with the fork must equal the forward without it bit for bit, twice.  (Second case:
+    full-size VideoMAE with the size bias, at a batch that forks by itself in eager mode.)"""
     tome, H = _hosts()
     from tome import _overlap
     from tome.patch import _common
     torch.manual_seed(0)
-    model = H["timesformer"].timesformer_base(8).to(DEV).to(torch.bfloat16).eval()
-    tome.patch.timesformer(model)
+    if host_name == "timesformer":
+        model = H["timesformer"].timesformer_base(8).to(DEV).to(torch.bfloat16).eval()
+        tome.patch.timesformer(model)
+        frames = 8
+    else:
+        model = H["videomae"].videomae_base(16).to(DEV).to(torch.bfloat16).eval()
+        tome.patch.videomae(model, prop_attn=True)
+        frames = 16
     model.r = 16
-    clip = [torch.rand(64, 3, 8, 224, 224, device=DEV).to(torch.bfloat16)]
+    clip = [torch.rand(batch, 3, frames, 224, 224, device=DEV).to(torch.bfloat16)]
     real_ready = _overlap.keys_ready
     forks = []
 
