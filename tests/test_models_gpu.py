@@ -931,6 +931,7 @@ def test_forward_reads_no_memory_it_did_not_write(host_name, batch, r):
     patch(model, **kw)
     model.r = r
     clip = [torch.rand(batch, 3, frames, 224, 224, device=DEV).to(torch.bfloat16)]
+    torch.cuda.reset_peak_memory_stats()
     with torch.no_grad():
         model(clip)
     torch.cuda.synchronize()
