@@ -859,6 +859,7 @@ def test_matching_beside_the_attention_on_the_side_stream(host_name, monkeypatch
         assert n_match == layers
         streams.clear()
         monkeypatch.setattr(_overlap, "ENABLED", True)
+        monkeypatch.setattr(_overlap, "MIN_WORK", int(6e7))  # (the default, whatever TOME_MATCH_STREAM_MIN says)
         model([clip])
         assert set(streams) == {main} and len(streams) == n_match  # too small a forward to fork in eager mode ...
         streams.clear()
@@ -896,7 +897,8 @@ def test_matching_beside_the_attention_on_the_side_stream(host_name, monkeypatch
         monkeypatch.undo()
         torch.cuda.synchronize()
     # captured: the side stream joins the capture through the two events (... but always inside a capture)
-    monkeypatch.setattr(_overlap, "ENABLED", True)  # (monkeypatch.undo() above restored the environment's setting)
+    monkeypatch.setattr(_overlap, "ENABLED", True)  # (monkeypatch.undo() above restored the environment's settings)
+    monkeypatch.setattr(_overlap, "MIN_WORK", int(6e7))
     main = torch.cuda.current_stream().cuda_stream
     seen = []
     real = _abi.match_keys
